@@ -1,0 +1,276 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU fp32 restatement of the reference UNet denoiser, written functionally over a
+flat ``state_dict`` (no nn.Module), so that it can be driven with the exact
+parameter names/shapes of the reference checkpoint format.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this file.  The product package ``diffusion_model_amd`` must
+never import it.
+
+Pinned by: ``tests/golden/*.npz`` (generated in the build container by
+``oracle/gen_golden.py``, which imports the real ``/root/reference/unet.py``) and
+the two notebook known-answer vectors.  The reference has
+no test-suite of its own, so there are no reference-held fixtures to pin to.
+
+Reference statements followed (file:line into /root/reference):
+  * sinusoidal table ............ unet.py:44-66
+  * ResBlock .................... unet.py:70-108
+  * self-attention .............. unet.py:110-139
+  * cross-attention ............. unet.py:141-220
+  * up/down-sample .............. unet.py:222-237
+  * UnetLayer ................... unet.py:239-285
+  * UNET ctor / forward ......... unet.py:287-356
+"""
+from __future__ import annotations
+
+import math
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class UNetSpec:
+    """Mirror of the reference constructor arguments (unet.py:288-302)."""
+    Channels: List[int] = field(default_factory=lambda: [64, 64, 128, 256, 128])
+    Upscales: List[bool] = field(default_factory=lambda: [False, False, True, True])
+    Attentions: List[bool] = field(default_factory=lambda: [False, True, True, False])
+    num_groups: int = 8
+    dropout_prob: float = 0.1
+    num_heads: int = 8
+    time_steps: int = 1000
+    input_channels: int = 1
+    output_channels: int = 1
+    use_cross_attention: bool = True
+    context_dim: Optional[int] = None
+    time_emb_dim: int = 256
+
+    @property
+    def num_layers(self) -> int:
+        return len(self.Channels) - 1
+
+    def has_cross(self) -> bool:
+        return bool(self.use_cross_attention and self.context_dim is not None)
+
+
+def sinusoid_table(time_steps: int, dim: int) -> Tensor:
+    """unet.py:49-53: E[p,2i]=sin(p*w_i), E[p,2i+1]=cos(p*w_i), w_i=exp(-2i ln(1e4)/dim)."""
+    p = torch.arange(0, time_steps, dtype=torch.float32)[:, None]
+    w = torch.exp(torch.arange(0, dim, 2).float() * (-math.log(10000.0) / dim))
+    tab = torch.zeros(time_steps, dim)
+    tab[:, 0::2] = torch.sin(p * w)
+    tab[:, 1::2] = torch.cos(p * w)
+    return tab
+
+
+def param_shapes(spec: UNetSpec) -> "Dict[str, tuple]":
+    """Names and shapes of every state_dict entry, in reference registration order."""
+    out: Dict[str, tuple] = {}
+    temb = spec.time_emb_dim
+    for i in range(spec.num_layers):
+        cin, cout = spec.Channels[i], spec.Channels[i + 1]
+        p = f"Layer{i + 1}."
+        out[p + "res_block.conv1.weight"] = (cout, cin, 3, 3)
+        out[p + "res_block.conv1.bias"] = (cout,)
+        out[p + "res_block.conv2.weight"] = (cout, cout, 3, 3)
+        out[p + "res_block.conv2.bias"] = (cout,)
+        out[p + "res_block.norm1.weight"] = (cin,)
+        out[p + "res_block.norm1.bias"] = (cin,)
+        out[p + "res_block.norm2.weight"] = (cout,)
+        out[p + "res_block.norm2.bias"] = (cout,)
+        if cin != cout:
+            out[p + "res_block.skip.weight"] = (cout, cin, 1, 1)
+            out[p + "res_block.skip.bias"] = (cout,)
+        out[p + "res_block.time_mlp.1.weight"] = (cout, temb)
+        out[p + "res_block.time_mlp.1.bias"] = (cout,)
+        if spec.Attentions[i]:
+            out[p + "attention.linear_qkv.weight"] = (3 * cout, cout)
+            out[p + "attention.linear_out.weight"] = (cout, cout)
+        if spec.has_cross():
+            out[p + "cross_attention.to_q.weight"] = (cout, cout)
+            out[p + "cross_attention.to_k.weight"] = (cout, spec.context_dim)
+            out[p + "cross_attention.to_v.weight"] = (cout, spec.context_dim)
+            out[p + "cross_attention.to_out.weight"] = (cout, cout)
+        if spec.Upscales[i]:
+            out[p + "upsample.conv.weight"] = (cout, cout, 3, 3)
+            out[p + "upsample.conv.bias"] = (cout,)
+            out[p + "conv.weight"] = (cout // 2, cout, 1, 1)
+            out[p + "conv.bias"] = (cout // 2,)
+        else:
+            out[p + "downsample.conv.weight"] = (cout, cout, 3, 3)
+            out[p + "downsample.conv.bias"] = (cout,)
+    cat = spec.Channels[-1] // 2 + spec.Channels[1]
+    out["input_conv.weight"] = (spec.Channels[0], spec.input_channels, 3, 3)
+    out["input_conv.bias"] = (spec.Channels[0],)
+    out["late_conv1.weight"] = (cat // 2, cat, 3, 3)
+    out["late_conv1.bias"] = (cat // 2,)
+    out["late_conv2.weight"] = (cat // 2, cat // 2, 3, 3)
+    out["late_conv2.bias"] = (cat // 2,)
+    out["output_conv.weight"] = (spec.output_channels, cat // 2, 1, 1)
+    out["output_conv.bias"] = (spec.output_channels,)
+    out["time_mlp.0.weight"] = (temb, temb)
+    out["time_mlp.0.bias"] = (temb,)
+    out["time_mlp.2.weight"] = (temb, temb)
+    out["time_mlp.2.bias"] = (temb,)
+    return out
+
+
+def closed_form_fill(shapes: "Dict[str, tuple]", gain: float = 1.0) -> Dict[str, Tensor]:
+    """Deterministic, RNG-free fill (reproducible on the GPU box without the reference):
+    value[i] = s * sin(0.37*i*(1+0.01*j) + 1.3*j) for the j-th tensor, with s chosen per
+    tensor kind so activations stay O(1)."""
+    import numpy as np
+
+    sd: Dict[str, Tensor] = {}
+    for j, (name, shape) in enumerate(shapes.items()):
+        n = 1
+        for s in shape:
+            n *= s
+        i = np.arange(n, dtype=np.float64)
+        base = np.sin(0.37 * i * (1.0 + 0.01 * j) + 1.3 * j)
+        if re.search(r"norm\d?\.weight$", name):
+            v = 1.0 + 0.1 * base
+        elif name.endswith(".bias"):
+            v = 0.05 * base
+        else:
+            fan_in = n // shape[0]
+            v = gain * math.sqrt(3.0 / fan_in) * base
+        sd[name] = torch.from_numpy(v.astype(np.float32)).reshape(shape).clone()
+    return sd
+
+
+def closed_form_weights(spec: UNetSpec, gain: float = 1.0) -> Dict[str, Tensor]:
+    """closed_form_fill over the whole UNet. output_conv is deliberately NON-zero (the
+    reference zero-inits it, unet.py:324-326, which makes every other gradient exactly
+    0 - useless for parity)."""
+    return closed_form_fill(param_shapes(spec), gain)
+
+
+def det_tensor(shape, seed: float = 0.0, scale: float = 1.0) -> Tensor:
+    """Closed-form pseudo-data: scale * sin(0.7311*i + 0.013*i*i mod 7 + seed)."""
+    import numpy as np
+
+    n = 1
+    for s in shape:
+        n *= s
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(0.7311 * i + np.mod(0.013 * i * i, 7.0) + seed) * scale
+    return torch.from_numpy(v.astype(np.float32)).reshape(shape).clone()
+
+
+# --------------------------------------------------------------------------- blocks
+def _gn_silu(x: Tensor, w: Tensor, b: Tensor, groups: int) -> Tensor:
+    return F.silu(F.group_norm(x, groups, w, b, eps=1e-5))
+
+
+def res_block(sd, p: str, x: Tensor, temb: Tensor, groups: int, drop_p: float = 0.0,
+              train: bool = False) -> Tensor:
+    """unet.py:92-108 (use_film=False branch)."""
+    h = F.conv2d(_gn_silu(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], groups),
+                 sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    tp = F.linear(F.silu(temb), sd[p + "time_mlp.1.weight"], sd[p + "time_mlp.1.bias"])
+    h = h + tp[:, :, None, None]
+    h = F.dropout(h, drop_p, training=train)
+    h = F.conv2d(_gn_silu(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"], groups),
+                 sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    if (p + "skip.weight") in sd:
+        x = F.conv2d(x, sd[p + "skip.weight"], sd[p + "skip.bias"])
+    return x + h
+
+
+def softmax_attention(q: Tensor, k: Tensor, v: Tensor, drop_p: float = 0.0,
+                      train: bool = False) -> Tensor:
+    """[B,H,N,d] x [B,H,L,d] -> [B,H,N,d]; explicit softmax(QK^T/sqrt(d))V
+    (the SDPA semantics called at unet.py:123/126 and :169/172)."""
+    s = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    pr = torch.softmax(s, dim=-1)
+    pr = F.dropout(pr, drop_p, training=train)
+    return torch.matmul(pr, v)
+
+
+def self_attention(sd, p: str, x: Tensor, heads: int, drop_p=0.0, train=False) -> Tensor:
+    """unet.py:128-139."""
+    B, C, H, W = x.shape
+    tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    qkv = F.linear(tok, sd[p + "linear_qkv.weight"]).reshape(B, H * W, 3, heads, C // heads)
+    q, k, v = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    o = softmax_attention(q, k, v, drop_p, train).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    o = F.linear(o, sd[p + "linear_out.weight"])
+    return o.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def cross_attention(sd, p: str, x: Tensor, ctx: Tensor, heads: int, drop_p=0.0,
+                    train=False) -> Tensor:
+    """unet.py:189-220; ctx is [B,D] (-> one token) or [B,L,D]."""
+    B, C, H, W = x.shape
+    tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    if ctx.dim() == 2:
+        ctx = ctx[:, None, :]
+    L = ctx.shape[1]
+    d = C // heads
+    q = F.linear(tok, sd[p + "to_q.weight"]).reshape(B, H * W, heads, d).permute(0, 2, 1, 3)
+    k = F.linear(ctx, sd[p + "to_k.weight"]).reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    v = F.linear(ctx, sd[p + "to_v.weight"]).reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    o = softmax_attention(q, k, v, drop_p, train).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    o = F.linear(o, sd[p + "to_out.weight"])
+    return o.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def unet_layer(sd, spec: UNetSpec, i: int, x: Tensor, temb: Tensor, ctx, train=False):
+    """unet.py:265-285. Returns (x_out, skip)."""
+    p = f"Layer{i + 1}."
+    dp = spec.dropout_prob if train else 0.0
+    x = res_block(sd, p + "res_block.", x, temb, spec.num_groups, dp, train)
+    res = x
+    if spec.Attentions[i]:
+        x = self_attention(sd, p + "attention.", x, spec.num_heads, dp, train)
+    if spec.has_cross() and ctx is not None:
+        x = cross_attention(sd, p + "cross_attention.", x, ctx, spec.num_heads, dp, train)
+    x = x + res
+    if spec.Upscales[i]:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = F.conv2d(x, sd[p + "upsample.conv.weight"], sd[p + "upsample.conv.bias"], padding=1)
+        x = F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"])
+        return x, x
+    skip = x
+    x = F.conv2d(x, sd[p + "downsample.conv.weight"], sd[p + "downsample.conv.bias"],
+                 stride=2, padding=1)
+    return x, skip
+
+
+def time_embedding(sd, spec: UNetSpec, t) -> Tensor:
+    """unet.py:59-66 + 339-340."""
+    tab = sinusoid_table(spec.time_steps, spec.time_emb_dim)
+    t = torch.as_tensor(t, dtype=torch.long).reshape(-1)
+    e = tab[t]
+    e = F.linear(e, sd["time_mlp.0.weight"], sd["time_mlp.0.bias"])
+    return F.linear(F.silu(e), sd["time_mlp.2.weight"], sd["time_mlp.2.bias"])
+
+
+def unet_forward(sd: Dict[str, Tensor], spec: UNetSpec, x: Tensor, t, context=None,
+                 train: bool = False) -> Tensor:
+    """unet.py:337-356."""
+    temb = time_embedding(sd, spec, t)
+    if context is not None and not torch.is_floating_point(context):
+        # legacy integer labels: only meaningful when no cross-attention exists (unet.py:271)
+        if spec.has_cross():
+            raise TypeError("integer context with cross-attention enabled")
+        context = None
+    skips = []
+    x = F.conv2d(x, sd["input_conv.weight"], sd["input_conv.bias"], padding=1)
+    half = spec.num_layers // 2
+    for i in range(half):
+        x, r = unet_layer(sd, spec, i, x, temb, context, train)
+        skips.append(r)
+    for i in range(half, spec.num_layers):
+        y, _ = unet_layer(sd, spec, i, x, temb, context, train)
+        x = torch.cat((y, skips.pop()), dim=1)
+    x = F.silu(F.conv2d(x, sd["late_conv1.weight"], sd["late_conv1.bias"], padding=1))
+    x = F.silu(F.conv2d(x, sd["late_conv2.weight"], sd["late_conv2.bias"], padding=1))
+    return F.conv2d(x, sd["output_conv.weight"], sd["output_conv.bias"])

@@ -1,0 +1,162 @@
+"""CPU: the oracle restatement (oracle/) against goldens generated from the REAL
+reference (oracle/gen_golden.py) and the notebook known answers."""
+import hashlib
+
+import pytest
+import torch
+
+from oracle import diffusion_ref as dref
+from oracle import unet_ref as oref
+from conftest import assert_close, load_golden
+
+FP32 = 1e-4
+
+
+def _sd(shapes, gain=1.0):
+    return oref.closed_form_fill(shapes, gain)
+
+
+def test_schedule_bit_exact_and_kats():
+    for T in (500, 1000):
+        for bmin, nm in ((1e-4, "stl10"), (0.0, "mnist")):
+            g = load_golden(f"schedule_cos_T{T}_{nm}")
+            b, a, ab = dref.cosine_schedule(T, 0.008, bmin)
+            assert torch.equal(b, g["beta"]) and torch.equal(a, g["alpha"]) and torch.equal(ab, g["alpha_bar"])
+    b, a, ab = dref.cosine_schedule(500)
+    # SURVEY 8(a10) known answers (torch-CPU fp32 of utils.py:274-287)
+    assert hashlib.sha256(b.numpy().tobytes()).hexdigest()[:16] == "bdb1d7a6e60e786d"
+    assert hashlib.sha256(ab.numpy().tobytes()).hexdigest()[:16] == "e9fc990280921744"
+    assert float(b[0]) == pytest.approx(9.99999975e-05, rel=1e-7)
+    assert float(b[1]) == pytest.approx(1.0675191879e-04, rel=1e-6)
+    assert float(b[499]) == pytest.approx(0.99900001, rel=1e-7)
+    assert float(ab[0]) == pytest.approx(0.99989998, rel=1e-7)
+    # notebook cell 3: linear schedule call(200) -> (0.6563, 0.0041)
+    lb, lab = dref.linear_schedule(1000)
+    assert round(float(lab[200]), 4) == 0.6563 and round(float(lb[200]), 4) == 0.0041
+
+
+def test_sinusoid_table():
+    g = load_golden("sinusoid")
+    tab = oref.sinusoid_table(1000, 256)
+    assert torch.equal(tab[g["rows"]], g["emb"])
+    # notebook cell 7: SinusoidalEmbeddings(100,64)(20) starts 0.9129, 0.4081, 0.6519, -0.7583
+    row = oref.sinusoid_table(100, 64)[20]
+    assert torch.equal(row, g["nb_cell7"])
+    assert [round(float(v), 4) for v in row[:4]] == [0.9129, 0.4081, 0.6519, -0.7583]
+
+
+def _check_grads(g, gp, names):
+    for n in names:
+        assert_close(gp[n], g["g." + n], FP32, n)
+
+
+def test_gn_silu():
+    g = load_golden("gn_silu")
+    sd = {k: v.requires_grad_() for k, v in _sd({"weight": (64,), "bias": (64,)}).items()}
+    x = g["x"].clone().requires_grad_()
+    y = oref._gn_silu(x, sd["weight"], sd["bias"], 8)
+    assert_close(y, g["y"], FP32, "y")
+    gx, gw, gb = torch.autograd.grad((y * g["G"]).sum(), [x, sd["weight"], sd["bias"]])
+    assert_close(gx, g["gx"], FP32, "gx")
+    assert_close(gw, g["g.weight"], FP32, "gw")
+    assert_close(gb, g["g.bias"], FP32, "gb")
+
+
+@pytest.mark.parametrize("tag,cin,cout", [("id64", 64, 64), ("skip64_128", 64, 128)])
+def test_resblock(tag, cin, cout):
+    g = load_golden(f"resblock_{tag}")
+    shapes = {k[2:]: tuple(v.shape) for k, v in g.items() if k.startswith("g.")}
+    # closed-form fill depends on registration ORDER: rebuild it in reference order
+    order = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "norm1.weight",
+             "norm1.bias", "norm2.weight", "norm2.bias"]
+    if cin != cout:
+        order += ["skip.weight", "skip.bias"]
+    order += ["time_mlp.1.weight", "time_mlp.1.bias"]
+    sd = {k: v.requires_grad_() for k, v in _sd({k: shapes[k] for k in order}).items()}
+    x = g["x"].clone().requires_grad_()
+    te = g["temb"].clone().requires_grad_()
+    y = oref.res_block(sd, "", x, te, 8)
+    assert_close(y, g["y"], FP32, "y")
+    grads = torch.autograd.grad((y * g["G"]).sum(), [x, te] + [sd[k] for k in order])
+    assert_close(grads[0], g["gx"], FP32, "gx")
+    assert_close(grads[1], g["gtemb"], FP32, "gtemb")
+    for k, gg in zip(order, grads[2:]):
+        assert_close(gg, g["g." + k], FP32, k)
+
+
+@pytest.mark.parametrize("tag,C", [("c128_hd16", 128), ("c256_hd32", 256)])
+def test_self_attention(tag, C):
+    g = load_golden(f"attention_{tag}")
+    order = ["linear_qkv.weight", "linear_out.weight"]
+    sd = {k: v.requires_grad_() for k, v in
+          _sd({"linear_qkv.weight": (3 * C, C), "linear_out.weight": (C, C)}, 2.0).items()}
+    x = g["x"].clone().requires_grad_()
+    y = oref.self_attention(sd, "", x, 8)
+    assert_close(y, g["y"], FP32, "y")
+    grads = torch.autograd.grad((y * g["G"]).sum(), [x] + [sd[k] for k in order])
+    assert_close(grads[0], g["gx"], FP32, "gx")
+    for k, gg in zip(order, grads[1:]):
+        assert_close(gg, g["g." + k], FP32, k)
+
+
+@pytest.mark.parametrize("tag,C", [("c64_hd8_L1", 64), ("c128_hd16_L4", 128), ("c256_hd32_L1", 256)])
+def test_cross_attention(tag, C):
+    g = load_golden(f"cross_{tag}")
+    order = ["to_q.weight", "to_k.weight", "to_v.weight", "to_out.weight"]
+    sd = {k: v.requires_grad_() for k, v in _sd(
+        {"to_q.weight": (C, C), "to_k.weight": (C, 512), "to_v.weight": (C, 512),
+         "to_out.weight": (C, C)}, 2.0).items()}
+    x = g["x"].clone().requires_grad_()
+    ctx = g["ctx"].clone().requires_grad_()
+    y = oref.cross_attention(sd, "", x, ctx, 8)
+    assert_close(y, g["y"], FP32, "y")
+    grads = torch.autograd.grad((y * g["G"]).sum(), [x, ctx] + [sd[k] for k in order],
+                                allow_unused=True)
+    # with ONE context token softmax==1: d/dx, d/dWq, d/dWk are round-off
+    if g["ctx"].dim() == 3 and g["ctx"].shape[1] > 1:
+        assert_close(grads[0], g["gx"], FP32, "gx")
+        assert_close(grads[2], g["g.to_q.weight"], FP32, "to_q")
+        assert_close(grads[3], g["g.to_k.weight"], FP32, "to_k")
+    else:
+        live = float(g["gctx"].abs().max())
+        for gg in (grads[0], grads[2], grads[3]):
+            assert gg is None or float(gg.abs().max()) < 1e-5 * live
+        assert float(g["gx"].abs().max()) < 1e-5 * live
+    assert_close(grads[1], g["gctx"], FP32, "gctx")
+    assert_close(grads[4], g["g.to_v.weight"], FP32, "to_v")
+    assert_close(grads[5], g["g.to_out.weight"], FP32, "to_out")
+
+
+@pytest.mark.parametrize("tag,spec_kw,hw", [
+    ("stl10_small", dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0), 32),
+    ("stl10_clip", dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0), 96),
+    ("stl10_noctx", dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0), 96),
+    ("mnist", dict(Attentions=[False] * 6, dropout_prob=0.0), 32),
+])
+def test_full_unet(tag, spec_kw, hw):
+    g = load_golden(f"unet_{tag}")
+    spec = oref.UNetSpec(**spec_kw)
+    sd = {k: v.requires_grad_() for k, v in oref.closed_form_weights(spec).items()}
+    x = g["x"].clone().requires_grad_()
+    ctx = g.get("ctx")
+    y = oref.unet_forward(sd, spec, x, g["t"], ctx)
+    assert_close(y, g["y"], FP32, "y")
+    names = list(sd)
+    grads = torch.autograd.grad((y * g["G"]).sum(), [x] + [sd[k] for k in names], allow_unused=True)
+    assert_close(grads[0], g["gx"], FP32, "gx")
+    gmax = max(float(g["gn." + k]) for k in names if "gn." + k in g)
+    for k, gg in zip(names, grads[1:]):
+        if "gn." + k not in g:
+            assert gg is None
+            continue
+        ref_n = float(g["gn." + k])
+        if ref_n < 1e-6 * gmax:  # dead path: round-off only
+            assert gg is None or float(torch.linalg.vector_norm(gg)) < 1e-5 * gmax
+            continue
+        assert float(torch.linalg.vector_norm(gg)) == pytest.approx(ref_n, rel=2e-4), k
+        f = gg.reshape(-1)
+        idx = (torch.arange(64) * 7919) % f.numel()
+        assert_close(f[idx], g["gs." + k], 2e-4, k, atol_frac=2e-4 * ref_n / (float(g["gs." + k].abs().max()) + 1e-30))
+    for k in g:
+        if k.startswith("gf."):
+            assert_close(dict(zip(names, grads[1:]))[k[3:]], g[k], FP32, k)
