@@ -1,0 +1,426 @@
+// Flash-style fused attention (forward + backward) for the UNet's self- and cross-attention:
+// 8 heads, head_dim in {8,16,32}, Nq in {576,2304,9216}, Nk = Nq (self) or the number of
+// context tokens (cross; 1 for the CLIP table).  No N x N matrix ever reaches memory.
+//
+// Register-resident P: the score tile is computed TRANSPOSED (S^T = K Q^T, keys on MFMA rows,
+// queries on the lane axis), so after the online softmax each lane already holds, for its
+// query, exactly the 8 keys per 32-key step that the P operand of the second MFMA
+// (O^T = V^T P^T) wants -- up to a fixed permutation of the reduction index, which is applied
+// to the V^T operand instead, for free, through the row addresses of ds_read_b64_tr_b16.
+// The same trick (with q and key swapped) serves dV/dK, and again dQ.
+//
+// With head dims this small the kernels are VALU/exp-bound, not MFMA-bound (64 MFMA flop per
+// score element against ~12 VALU ops); see DESIGN.md.
+//
+// Reference semantics replaced: F.scaled_dot_product_attention(q,k,v,dropout_p) with scale
+// 1/sqrt(hd), non-causal (unet.py:119-126,136,165-172,214) and its autograd backward.
+#include "dm_common.h"
+
+namespace {
+
+constexpr int RS = 80;         // LDS row stride (bytes) of a [rows][32 d] bf16 block (64 B + 16 pad)
+constexpr float NEG = -1e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnParams {
+  const bf16* q; long ldq; const bf16* k; long ldk; const bf16* v; long ldv;
+  bf16* o; long ldo; float* lse;
+  const bf16* d_o; long lddo; bf16* dq; long lddq; bf16* dk; long lddk; bf16* dv; long lddv;
+  float* delta;
+  int B, H, Nq, Nk, hd;
+  float scale;
+  uint64_t seed; uint32_t thresh; float inv_keep;
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = (bf16)a[j]; r[4 + j] = (bf16)b[j]; }
+  return r;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)0.f;
+  return r;
+}
+// row fragment straight from global: 8 head-dim elements [8g, 8g+8) of token `tok`
+__device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, long tok, bool tok_ok, int hoff, int hd,
+                                                int g) {
+  if (!tok_ok || 8 * g >= hd) return zero8();
+  return *reinterpret_cast<const bf16x8*>(base + tok * ld + hoff + 8 * g);
+}
+// stage 64 rows x 32 (padded) head-dim of one head into LDS; rows >= n_rows and dims >= hd are zero
+__device__ __forceinline__ void stage_block(char* dst, const bf16* base, long ld, long tok0, long n_tok, int hoff,
+                                            int hd, int tid) {
+  const int row = tid >> 2, pc = tid & 3;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (tok0 + row < n_tok && pc * 8 < hd)
+    v = *reinterpret_cast<const u32x4*>(base + (tok0 + row) * ld + hoff + pc * 8);
+  *reinterpret_cast<u32x4*>(dst + row * RS + pc * 16) = v;
+}
+
+// ---------------------------------------------------------------- forward
+template <int DT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sK[64 * RS];
+  __shared__ __attribute__((aligned(16))) char sV[64 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = p.scale * LOG2E;
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+
+  bf16x8 qf[2];
+  int qi[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qi[qt] = q0 + qt * 16 + li;
+    qf[qt] = load_row_frag(p.q, p.ldq, qbase + qi[qt], qi[qt] < p.Nq, hoff, p.hd, g);
+  }
+  float m[2] = {NEG, NEG}, l[2] = {0.f, 0.f};
+  f32x4 acc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (p.Nk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    stage_block(sK, p.k, p.ldk, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
+    stage_block(sV, p.v, p.ldv, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
+    __syncthreads();
+    f32x4 st[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float bm = NEG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 64 + kt * 16 + 4 * g + r;
+          const float s = (key < p.Nk) ? st[kt][qt][r] * c : NEG;
+          st[kt][qt][r] = s;
+          bm = fmaxf(bm, s);
+        }
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float mn = fmaxf(m[qt], bm);
+      const float alpha = exp2f(m[qt] - mn);
+      m[qt] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = exp2f(st[kt][qt][r] - mn);
+          ps += pv;
+          if (p.thresh) {
+            const int key = kb * 64 + kt * 16 + 4 * g + r;
+            const uint64_t idx = ((uint64_t)bh * p.Nq + qi[qt]) * p.Nk + key;
+            pv = dm_keep(p.seed, idx, p.thresh) ? pv * p.inv_keep : 0.f;
+          }
+          st[kt][qt][r] = pv;
+        }
+      l[qt] = l[qt] * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt][qt] *= alpha;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int qq = li >> 2, pp = li & 3;
+        const char* a0 = sV + (ks * 32 + 4 * g + qq) * RS + dt * 32 + pp * 8;
+        const bf16x8 vT = tr_pair(a0, a0 + 16 * RS);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, pack8(st[2 * ks][qt], st[2 * ks + 1][qt]),
+                                                                acc[dt][qt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.f / lt;
+    if (qi[qt] < p.Nq) {
+      if (g == 0 && p.lse) p.lse[(long)bh * p.Nq + qi[qt]] = (m[qt] + log2f(lt)) * LN2;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * g;
+        if (d < p.hd) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[dt][qt][r] * inv);
+          *reinterpret_cast<bf16x4*>(p.o + (qbase + qi[qt]) * p.ldo + hoff + d) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]
+__global__ void attn_delta_kernel(const AttnParams p) {
+  const long total = (long)p.B * p.H * p.Nq;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % p.Nq);
+    const int bh = (int)(i / p.Nq);
+    const int b = bh / p.H, h = bh % p.H;
+    const bf16* o = p.o + ((long)b * p.Nq + q) * p.ldo + h * p.hd;
+    const bf16* d = p.d_o + ((long)b * p.Nq + q) * p.lddo + h * p.hd;
+    float s = 0.f;
+    for (int j = 0; j < p.hd; j += 8) {
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + j);
+      const bf16x8 dv = *reinterpret_cast<const bf16x8*>(d + j);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) s += (float)ov[t] * (float)dv[t];
+    }
+    p.delta[i] = s;
+  }
+}
+
+// dK, dV: one wave = 16 keys (MFMA columns), workgroup = 64 keys, loop over query blocks of 64.
+template <int DT>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sQ[64 * RS];
+  __shared__ __attribute__((aligned(16))) char sO[64 * RS];
+  __shared__ float sL[64], sD[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
+  const int key = blockIdx.x * 64 + wave * 16 + li;
+  const bool key_ok = key < p.Nk;
+  const float c = p.scale * LOG2E;
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  const bf16x8 kfrag = load_row_frag(p.k, p.ldk, kbase + key, key_ok, hoff, p.hd, g);
+  const bf16x8 vfrag = load_row_frag(p.v, p.ldv, kbase + key, key_ok, hoff, p.hd, g);
+  f32x4 dkT[DT], dvT[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqb = (p.Nq + 63) / 64;
+  for (int qb = 0; qb < nqb; ++qb) {
+    __syncthreads();
+    stage_block(sQ, p.q, p.ldq, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
+    stage_block(sO, p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
+    if (tid < 64) {
+      const int q = qb * 64 + tid;
+      sL[tid] = (q < p.Nq) ? p.lse[(long)bh * p.Nq + q] * LOG2E : 0.f;
+      sD[tid] = (q < p.Nq) ? p.delta[(long)bh * p.Nq + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 pt[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + g * 16);
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(sO + (qt * 16 + li) * RS + g * 16);
+      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qt * 16 + 4 * g + r;
+        const int q = qb * 64 + ql;
+        float pv = (key_ok && q < p.Nq) ? exp2f(s[r] * c - sL[ql]) : 0.f;
+        float pd = pv, dpv = dp[r];
+        if (p.thresh) {
+          const uint64_t idx = ((uint64_t)bh * p.Nq + q) * p.Nk + key;
+          const bool keep = dm_keep(p.seed, idx, p.thresh);
+          pd = keep ? pv * p.inv_keep : 0.f;
+          dpv = keep ? dpv * p.inv_keep : 0.f;
+        }
+        pt[qt][r] = pd;
+        ds[qt][r] = pv * (dpv - sD[ql]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pB = pack8(pt[2 * ks], pt[2 * ks + 1]);
+      const bf16x8 dsB = pack8(ds[2 * ks], ds[2 * ks + 1]);
+      const int qq = li >> 2, pp = li & 3;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (ks * 32 + 4 * g + qq) * RS + dt * 32 + pp * 8;
+        const bf16x8 doT = tr_pair(sO + off, sO + off + 16 * RS);
+        dvT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, pB, dvT[dt], 0, 0, 0);
+        const bf16x8 qT = tr_pair(sQ + off, sQ + off + 16 * RS);
+        dkT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB, dkT[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (key_ok) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + 4 * g;
+      if (d < p.hd) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[dt][r] * p.scale); ov[r] = (bf16)dvT[dt][r]; }
+        *reinterpret_cast<bf16x4*>(p.dk + (kbase + key) * p.lddk + hoff + d) = ok;
+        *reinterpret_cast<bf16x4*>(p.dv + (kbase + key) * p.lddv + hoff + d) = ov;
+      }
+    }
+  }
+}
+
+// dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
+template <int DT>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sK[64 * RS];
+  __shared__ __attribute__((aligned(16))) char sV[64 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = p.scale * LOG2E;
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  bf16x8 qf[2], dof[2];
+  int qi[2];
+  float Lq[2], Dq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qi[qt] = q0 + qt * 16 + li;
+    const bool ok = qi[qt] < p.Nq;
+    qf[qt] = load_row_frag(p.q, p.ldq, qbase + qi[qt], ok, hoff, p.hd, g);
+    dof[qt] = load_row_frag(p.d_o, p.lddo, qbase + qi[qt], ok, hoff, p.hd, g);
+    Lq[qt] = ok ? p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : 0.f;
+    Dq[qt] = ok ? p.delta[(long)bh * p.Nq + qi[qt]] : 0.f;
+  }
+  f32x4 dqT[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) dqT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkb = (p.Nk + 63) / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    stage_block(sK, p.k, p.ldk, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
+    stage_block(sV, p.v, p.ldv, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
+    __syncthreads();
+    f32x4 ds[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (kt * 16 + li) * RS + g * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 64 + kt * 16 + 4 * g + r;
+          const float pv = (key < p.Nk && qi[qt] < p.Nq) ? exp2f(s[r] * c - Lq[qt]) : 0.f;
+          float dpv = dp[r];
+          if (p.thresh) {
+            const uint64_t idx = ((uint64_t)bh * p.Nq + qi[qt]) * p.Nk + key;
+            dpv = dm_keep(p.seed, idx, p.thresh) ? dpv * p.inv_keep : 0.f;
+          }
+          ds[kt][qt][r] = pv * (dpv - Dq[qt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int qq = li >> 2, pp = li & 3;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (ks * 32 + 4 * g + qq) * RS + dt * 32 + pp * 8;
+        const bf16x8 kT = tr_pair(sK + off, sK + off + 16 * RS);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          dqT[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, pack8(ds[2 * ks][qt], ds[2 * ks + 1][qt]),
+                                                                dqT[dt][qt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qi[qt] >= p.Nq) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + 4 * g;
+      if (d < p.hd) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)(dqT[dt][qt][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(p.dq + (qbase + qi[qt]) * p.lddq + hoff + d) = o;
+      }
+    }
+  }
+}
+
+int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
+  DM_REQUIRE(a && a->q && a->k && a->v && a->o && a->lse);
+  DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32);
+  DM_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
+  DM_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0);
+  DM_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f);
+  if (bwd) {
+    DM_REQUIRE(a->d_o && a->dq && a->dk && a->dv && a->delta);
+    DM_REQUIRE(a->lddo % 8 == 0 && a->ldo % 8 == 0 && a->lddq % 4 == 0 && a->lddk % 4 == 0 && a->lddv % 4 == 0);
+  }
+  p.q = (const bf16*)a->q; p.ldq = a->ldq; p.k = (const bf16*)a->k; p.ldk = a->ldk;
+  p.v = (const bf16*)a->v; p.ldv = a->ldv; p.o = (bf16*)a->o; p.ldo = a->ldo; p.lse = a->lse;
+  p.d_o = (const bf16*)a->d_o; p.lddo = a->lddo; p.dq = (bf16*)a->dq; p.lddq = a->lddq;
+  p.dk = (bf16*)a->dk; p.lddk = a->lddk; p.dv = (bf16*)a->dv; p.lddv = a->lddv; p.delta = a->delta;
+  p.B = a->B; p.H = a->heads; p.Nq = a->Nq; p.Nk = a->Nk; p.hd = a->hd; p.scale = a->scale;
+  p.seed = a->drop_seed;
+  p.thresh = a->drop_p > 0.f ? (uint32_t)((double)a->drop_p * 4294967296.0) : 0u;
+  p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
+  AttnParams p{};
+  const int rc = fill(p, a, false);
+  if (rc != DM_OK) return rc;
+  const dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+  if (p.hd > 16) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
+  AttnParams p{};
+  const int rc = fill(p, a, true);
+  if (rc != DM_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)p.B * p.H * p.Nq;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
+  DM_LAUNCH_CHECK();
+  const dim3 gkv((p.Nk + 63) / 64, p.B * p.H), gq((p.Nq + 127) / 128, p.B * p.H);
+  if (p.hd > 16) {
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<2>, gkv, dim3(256), 0, st, p);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_q_kernel<2>, gq, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<1>, gkv, dim3(256), 0, st, p);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_q_kernel<1>, gq, dim3(256), 0, st, p);
+  }
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

@@ -1,0 +1,429 @@
+// Implicit-GEMM convolution / GEMM forward (and data-gradient) for gfx950.
+//
+// Data layout: activations NHWC bf16 with an explicit pixel stride (ld*), so producers
+// can write straight into channel slices of a concat buffer; weights are a bf16 shadow
+// of the fp32 OIHW master, pre-packed in MFMA-fragment order (dm_pack_weight) so one
+// B-stage is a contiguous, lane-linear 8 KiB block.
+//
+// Kernel structure (one workgroup = 256 threads = 4 waves, 2 workgroups / CU):
+//   for each 64-channel chunk of Cin:
+//     stage the input HALO PATCH ((TH+2)x(TW+2) pixels x 64 ch) into LDS once,
+//     then sweep the 9 taps: every tap re-reads the patch at a shifted LDS address
+//     (9x LDS reuse of each staged byte), weights stream through a double-buffered
+//     8 KiB LDS stage.
+//   MFMA: v_mfma_f32_16x16x32_bf16, weights as the A operand (rows = cout) and pixels
+//   as the B operand (cols = pixel), so each lane ends up with 4 consecutive output
+//   channels of one pixel -> 8-byte NHWC stores, per-channel bias/temb adds stay in-lane.
+//   The patch pixel stride (160 B / 144 B) and pitch are chosen so that every
+//   ds_read_b128 fragment read is bank-conflict free (brute-forced against the gfx950
+//   lane-group table).
+//
+// Reference semantics replaced: nn.Conv2d 3x3 s1/s2 p1, nearest-x2 + conv3x3
+// (unet.py:74-75,225-229,234,317-319), nn.Conv2d 1x1 / nn.Linear (unet.py:79,113-114,
+// 160-163,261,320,333-335) and their autograd data-gradients.
+#include "dm_common.h"
+
+namespace {
+
+enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UP = 2, MODE_ZI = 3, MODE_GEMM = 4 };
+
+struct ConvParams {
+  const bf16* x; long ldx;       // input pixel stride (elements)
+  const char* w;                 // packed weights
+  const float* bias;             // [Cout] or null
+  const float* chan_add;         // [B, Cout] fp32 (time-embedding projection) or null
+  const bf16* res; long ldr;     // residual to add (same pixel indexing as y) or null
+  bf16* y; long ldy;             // bf16 output (null if yf used)
+  float* yf; long ldyf;          // optional fp32 output
+  int B, Hi, Wi, Cin, Cout, Ho, Wo;
+  int tiles_h, tiles_w;
+  long M;                        // GEMM mode: rows
+  int rows_per_batch;            // GEMM mode: rows per chan_add batch index
+  int n_valid;                   // number of real output channels to store
+  int pool2;                     // sum 2x2 output pixels (dgrad of nearest-x2)
+  int act_silu_in;               // apply SiLU to the input while staging
+  // dropout on the output (after bias/chan_add, before res): keep iff rng>=thresh, scale
+  uint64_t drop_seed; uint32_t drop_thresh; float drop_scale;
+};
+
+template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
+  constexpr int TAPS = (MODE == MODE_GEMM) ? 1 : 9;
+  constexpr int PH = (MODE == MODE_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int PW = (MODE == MODE_GEMM) ? TW : ((S == 1) ? TW + 2 : 2 * TW + 1);
+  constexpr int MT = TH * TW / 64;  // m-tiles (16 pixels) per wave
+  constexpr int A_BYTES = ((PH * PITCH * STRIDE + 15) / 16) * 16;
+  constexpr int KSPS = (NT <= 4) ? 2 : 1;       // k-steps (of 32) per B stage
+  constexpr int B_STAGE = KSPS * NT * 1024;     // bytes
+  constexpr int B_PIECES = B_STAGE / 16;        // 16-byte pieces per stage
+  constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;
+  constexpr int NS = TAPS * 2 / KSPS;           // stages per channel chunk
+  static_assert(TH * TW % 64 == 0, "tile must hold a whole number of m-tiles per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b, h0, w0;
+  long m0 = 0;
+  if constexpr (MODE == MODE_GEMM) {
+    m0 = (long)blockIdx.x * (TH * TW);
+    b = 0; h0 = 0; w0 = 0;
+  } else {
+    int tile = blockIdx.x;
+    const int tw_i = tile % p.tiles_w; tile /= p.tiles_w;
+    const int th_i = tile % p.tiles_h;
+    b = tile / p.tiles_h;
+    h0 = th_i * TH; w0 = tw_i * TW;
+  }
+  const int nb = blockIdx.y;
+  const int NTG = p.Cout >> 4;
+
+  int aoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = (wave * MT + mt) * 16 + (lane & 15);
+    const int r = q / TW, c = q % TW;
+    aoff[mt] = ((S * r) * PITCH + S * c) * STRIDE + (lane >> 4) * 16;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ncc = (p.Cin + 63) >> 6;
+  const int vh0 = (MODE == MODE_S2) ? 2 * h0 - 1 : h0 - 1;
+  const int vw0 = (MODE == MODE_S2) ? 2 * w0 - 1 : w0 - 1;
+
+  for (int cc = 0; cc < ncc; ++cc) {
+    __syncthreads();
+    // ---- stage the input patch for this channel chunk
+    for (int idx = tid; idx < PH * PW * 8; idx += 256) {
+      const int piece = idx & 7;
+      const int pp = idx >> 3;
+      const int pr = pp / PW, pc = pp % PW;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      bool valid;
+      long src;
+      const int ch = cc * 64 + piece * 8;
+      if constexpr (MODE == MODE_GEMM) {
+        const long m = m0 + pp;
+        valid = (m < p.M) && (ch < p.Cin);
+        src = m * p.ldx + ch;
+      } else {
+        const int vh = vh0 + pr, vw = vw0 + pc;
+        int sh = vh, sw = vw;
+        if constexpr (MODE == MODE_UP) {
+          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+          sh = vh >> 1; sw = vw >> 1;
+        } else if constexpr (MODE == MODE_ZI) {
+          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi) &&
+                  (((vh | vw) & 1) == 0);
+          sh = vh >> 1; sw = vw >> 1;
+        } else {
+          valid = (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+        }
+        src = (((long)b * p.Hi + sh) * p.Wi + sw) * p.ldx + ch;
+      }
+      if (valid) {
+        v = *reinterpret_cast<const u32x4*>(p.x + src);
+        if (p.act_silu_in) {
+          bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
+          v = __builtin_bit_cast(u32x4, h);
+        }
+      }
+      *reinterpret_cast<u32x4*>(sA + (pr * PITCH + pc) * STRIDE + piece * 16) = v;
+    }
+    // ---- weight stages
+    auto stage_src = [&](int s, int piece) -> const char* {
+      int tap, ks, rem;
+      if constexpr (KSPS == 2) {
+        tap = s; ks = piece / (NT * 64); rem = piece % (NT * 64);
+      } else {
+        tap = s >> 1; ks = s & 1; rem = piece;
+      }
+      const int nt = rem >> 6, ln = rem & 63;
+      const long off = ((((long)(cc * TAPS + tap) * 2 + ks) * NTG + nb * NT + nt) * 64 + ln) * 16;
+      return p.w + off;
+    };
+    u32x4 breg[B_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+      const int piece = tid + i * 256;
+      if (piece < B_PIECES) breg[i] = *reinterpret_cast<const u32x4*>(stage_src(0, piece));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+      const int piece = tid + i * 256;
+      if (piece < B_PIECES) *reinterpret_cast<u32x4*>(sB + piece * 16) = breg[i];
+    }
+    __syncthreads();
+
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) {
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+          const int piece = tid + i * 256;
+          if (piece < B_PIECES) breg[i] = *reinterpret_cast<const u32x4*>(stage_src(s + 1, piece));
+        }
+      }
+      const char* sBc = sB + (s & 1) * B_STAGE;
+#pragma unroll
+      for (int ksl = 0; ksl < KSPS; ++ksl) {
+        const int tap = (KSPS == 2) ? s : (s >> 1);
+        const int ks = (KSPS == 2) ? ksl : (s & 1);
+        const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+        const int tapoff = (kh * PITCH + kw) * STRIDE + ks * 64;
+        bf16x8 av[MT], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt], av[mt], acc[mt][nt], 0, 0, 0);
+      }
+      if (s + 1 < NS) {
+        char* sBn = sB + ((s + 1) & 1) * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+          const int piece = tid + i * 256;
+          if (piece < B_PIECES) *reinterpret_cast<u32x4*>(sBn + piece * 16) = breg[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane holds couts [cq..cq+3] of pixel (lane&15) of each m-tile
+  const int cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (nb * NT + nt) * 16 + cq;
+    if (co >= p.n_valid) continue;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    if (p.pool2) {
+      if constexpr (MODE != MODE_GEMM && TW == 16 && (MT % 2) == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt += 2) {
+          f32x4 v = acc[mt][nt] + acc[mt + 1][nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], 1, 64);
+          if ((lane & 1) == 0) {
+            const int r = wave * MT + mt;  // even output row of the pair
+            const int oh = (h0 + r) >> 1, ow = (w0 + (lane & 15)) >> 1;
+            const long pix = ((long)b * (p.Ho >> 1) + oh) * (p.Wo >> 1) + ow;
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)(v[j] + bias4[j]);
+            *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int q = (wave * MT + mt) * 16 + (lane & 15);
+      long pix;
+      int bb = b;
+      if constexpr (MODE == MODE_GEMM) {
+        pix = m0 + q;
+        if (pix >= p.M) continue;
+        bb = (int)(pix / p.rows_per_batch);
+      } else {
+        const int r = q / TW, c = q % TW;
+        pix = ((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c);
+      }
+      f32x4 v = acc[mt][nt] + bias4;
+      if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
+      if (p.drop_thresh) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = dm_keep(p.drop_seed, (uint64_t)pix * p.Cout + co + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+      }
+      if (p.res) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+      }
+      if (p.yf) {
+        if (co + 3 < p.n_valid) {
+          *reinterpret_cast<f32x4*>(p.yf + pix * p.ldyf + co) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.n_valid) p.yf[pix * p.ldyf + co + j] = v[j];
+        }
+      }
+      if (p.y) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
+      }
+    }
+  }
+}
+
+template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+  constexpr int PH = (MODE == MODE_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int A_BYTES = ((PH * PITCH * STRIDE + 15) / 16) * 16;
+  constexpr int KSPS = (NT <= 4) ? 2 : 1;
+  constexpr int LDS = A_BYTES + 2 * KSPS * NT * 1024;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU must fit in 160 KiB of LDS");
+  auto k = conv_mfma_kernel<TH, TW, S, PITCH, STRIDE, NT, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid;
+  if (MODE == MODE_GEMM) grid = dim3((unsigned)((p.M + TH * TW - 1) / (TH * TW)), (unsigned)(p.Cout / (16 * NT)));
+  else grid = dim3((unsigned)(p.B * p.tiles_h * p.tiles_w), (unsigned)(p.Cout / (16 * NT)));
+  hipLaunchKernelGGL(k, grid, dim3(256), LDS, st, p);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ------------------------------------------------------------------ weight packing
+// dst element (kstep, ntg, lane, j):  n = ntg*16 + (lane&15), kk = kstep*32 + 8*(lane>>4) + j,
+// kstep = (cc*TAPS + tap)*2 + ks, channel k = cc*64 + ks*32 + 8*(lane>>4) + j.
+//   transpose = 0: value = W[n][k][kh][kw]          (forward; W is [N][K][kh][kw] fp32)
+//   transpose = 1: value = W[k][n][2-kh][2-kw]      (data-gradient; W is [K][N][kh][kw])
+// Out-of-range n (>= N) or k (>= K) pack as zero (padding to 16 / 64).
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int N, int K,
+                                   int taps, int transpose, int Npad, int Kpad) {
+  const long total = (long)Npad * Kpad * taps;
+  const int NTG = Npad >> 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    const int ln = (int)((i >> 3) & 63);
+    long r = i >> 9;
+    const int ntg = (int)(r % NTG); r /= NTG;
+    const int ks = (int)(r & 1); r >>= 1;
+    const int tap = (int)(r % taps);
+    const int cc = (int)(r / taps);
+    const int n = ntg * 16 + (ln & 15);
+    const int k = cc * 64 + ks * 32 + 8 * (ln >> 4) + j;
+    float v = 0.f;
+    if (n < N && k < K) {
+      const int kh = tap / 3, kw = tap % 3;
+      if (!transpose) v = w[((long)n * K + k) * taps + tap];
+      else v = (taps == 9) ? w[((long)k * N + n) * 9 + (2 - kh) * 3 + (2 - kw)] : w[(long)k * N + n];
+    }
+    dst[i] = (bf16)v;
+  }
+}
+
+}  // namespace
+
+extern "C" long dm_packed_weight_bytes(int N, int K, int taps) {
+  const long Npad = (N + 15) / 16 * 16, Kpad = (K + 63) / 64 * 64;
+  return Npad * Kpad * taps * 2;
+}
+
+extern "C" int dm_pack_weight(const float* w, void* dst, int N, int K, int taps, int transpose,
+                              dm_stream_t stream) {
+  DM_REQUIRE(w && dst && N > 0 && K > 0 && (taps == 1 || taps == 9));
+  const int Npad = (N + 15) / 16 * 16, Kpad = (K + 63) / 64 * 64;
+  const long total = (long)Npad * Kpad * taps;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16*)dst, N, K,
+                     taps, transpose, Npad, Kpad);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// mode: 0 = 3x3 s1 p1, 1 = 3x3 s2 p1, 2 = nearest-x2 then 3x3 s1 p1, 3 = zero-insert-x2 then
+// 3x3 s1 p1 (data-gradient of mode 1 with transposed+flipped weights).
+extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->w && (a->y || a->yf));
+  DM_REQUIRE(a->Cin % 64 == 0 && a->Cout % 64 == 0 && a->B > 0);
+  DM_REQUIRE(a->ldx % 8 == 0 && a->ldx >= a->Cin);
+  DM_REQUIRE(!a->y || (a->ldy % 4 == 0));
+  DM_REQUIRE(!a->res || (a->ldr % 4 == 0));
+  DM_REQUIRE(a->mode >= 0 && a->mode <= 3);
+  ConvParams p{};
+  p.x = (const bf16*)a->x; p.ldx = a->ldx; p.w = (const char*)a->w; p.bias = a->bias;
+  p.chan_add = a->chan_add; p.res = (const bf16*)a->res; p.ldr = a->ldr;
+  p.y = (bf16*)a->y; p.ldy = a->ldy; p.yf = a->yf; p.ldyf = a->ldyf;
+  p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
+  p.pool2 = a->pool2; p.act_silu_in = a->act_silu_in;
+  p.drop_seed = a->drop_seed; p.drop_scale = 1.0f;
+  p.drop_thresh = 0;
+  if (a->drop_p > 0.f) {
+    DM_REQUIRE(a->drop_p < 1.f);
+    p.drop_thresh = (uint32_t)((double)a->drop_p * 4294967296.0);
+    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = a->mode;
+  if (mode == 1) { p.Ho = a->H / 2; p.Wo = a->W / 2; DM_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0); }
+  else if (mode == 2 || mode == 3) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
+  else { p.Ho = a->H; p.Wo = a->W; }
+  DM_REQUIRE(!p.pool2 || (p.Ho % 16 == 0 && p.Wo % 16 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
+  const bool wide = (a->Cout % 128 == 0);
+#define DM_GO(TH, TW, S, PITCH, STRIDE, MODE)                                          \
+  do {                                                                                 \
+    p.tiles_h = p.Ho / TH; p.tiles_w = p.Wo / TW;                                      \
+    if (wide) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);            \
+    return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
+  } while (0)
+  if (mode == 1) {
+    DM_REQUIRE(p.Ho % 8 == 0 && p.Wo % 8 == 0);
+    DM_GO(8, 8, 2, 24, 144, MODE_S2);
+  }
+  if (p.Ho % 16 == 0 && p.Wo % 16 == 0) {
+    if (mode == 0) DM_GO(16, 16, 1, 18, 160, MODE_S1);
+    if (mode == 2) DM_GO(16, 16, 1, 18, 160, MODE_UP);
+    DM_GO(16, 16, 1, 18, 160, MODE_ZI);
+  }
+  if (p.Ho % 8 == 0 && p.Wo % 24 == 0) {
+    if (mode == 0) DM_GO(8, 24, 1, 32, 160, MODE_S1);
+    if (mode == 2) DM_GO(8, 24, 1, 32, 160, MODE_UP);
+    DM_GO(8, 24, 1, 32, 160, MODE_ZI);
+  }
+  if (p.Ho % 8 == 0 && p.Wo % 8 == 0) {  // generic small images (tests, MNIST 32x32 path is 16-divisible)
+    if (mode == 0) DM_GO(8, 8, 1, 10, 160, MODE_S1);
+    if (mode == 2) DM_GO(8, 8, 1, 10, 160, MODE_UP);
+    DM_GO(8, 8, 1, 10, 160, MODE_ZI);
+  }
+#undef DM_GO
+  return DM_ERR_ARG;
+}
+
+// Y[M, N] = X[M, K] * W[N, K]^T (+bias)(+chan_add[row / rows_per_batch])(+res); bf16 in, fp32 accumulate.
+extern "C" int dm_gemm(const dm_gemm_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->w && (a->y || a->yf) && a->M > 0);
+  DM_REQUIRE(a->K % 8 == 0 && a->N % 16 == 0 && a->ldx % 8 == 0);
+  DM_REQUIRE(!a->y || (a->ldy % 4 == 0));
+  DM_REQUIRE(!a->res || (a->ldr % 4 == 0));
+  ConvParams p{};
+  p.x = (const bf16*)a->x; p.ldx = a->ldx; p.w = (const char*)a->w; p.bias = a->bias;
+  p.chan_add = a->chan_add; p.res = (const bf16*)a->res; p.ldr = a->ldr;
+  p.y = (bf16*)a->y; p.ldy = a->ldy; p.yf = a->yf; p.ldyf = a->ldyf;
+  p.M = a->M; p.Cin = a->K; p.Cout = a->N; p.B = 1;
+  p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1 << 30;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
+  p.act_silu_in = a->act_silu_in;
+  p.drop_thresh = 0; p.drop_scale = 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->N % 128 == 0) return launch_conv<16, 16, 1, 16, 160, 8, MODE_GEMM>(p, st);
+  if (a->N % 64 == 0) return launch_conv<16, 16, 1, 16, 160, 4, MODE_GEMM>(p, st);
+  if (a->N % 32 == 0) return launch_conv<16, 16, 1, 16, 160, 2, MODE_GEMM>(p, st);
+  return launch_conv<16, 16, 1, 16, 160, 1, MODE_GEMM>(p, st);
+}

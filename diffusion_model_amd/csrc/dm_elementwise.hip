@@ -1,0 +1,399 @@
+// HBM-bound elementwise / layout kernels: NCHW fp32 <-> NHWC bf16, strided add, SiLU backward,
+// q-sample + v-target, weighted MSE loss + gradient, fused CFG + v->eps + DDPM/eta step,
+// fused clip + AdamW + EMA over a flat fp32 parameter buffer, squared-norm reduction.
+//
+// Reference semantics replaced (file:line into the reference):
+//   q-sample / v-target ........ main_stl10.py:456-465
+//   loss ....................... main_stl10.py:477-482
+//   CFG combine, v->eps ........ main_stl10.py:130-136
+//   DDPM/eta step, final step .. visualization.py:92-109,144-152
+//   clip_grad_norm_/AdamW/EMA .. main_stl10.py:508-510 (torch + timm semantics)
+#include "dm_common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline int ew_grid(long n_vec) {
+  long g = (n_vec + EW_BLOCK - 1) / EW_BLOCK;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// x: [B, C, H, W] fp32 -> y: [B, H*W, ld] bf16 (channels >= C zero-filled up to Cpad)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int C, int HW,
+                                    long ldy, int Cpad) {
+  const long total = (long)B * HW * (Cpad >> 3);
+  const int vpp = Cpad >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpp);
+    const long bp = i / vpp;
+    const int pix = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cv * 8 + j;
+      o[j] = (bf16)(c < C ? x[((long)b * C + c) * HW + pix] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(y + bp * ldy + cv * 8) = o;
+  }
+}
+
+// x: [B*HW, ld] (bf16 or fp32) -> y: [B, C, HW] fp32 ; accumulate: y += (used for nothing else)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, long ldx, float* __restrict__ y, int B, int C, int HW) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % HW);
+    const long bc = i / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    y[i] = (float)x[((long)b * HW + pix) * ldx + c];
+  }
+}
+
+// out[p][c] = a[p][c] + b[p][c] over [P, C] with pixel strides
+__global__ void add_kernel(const bf16* __restrict__ a, long lda, const bf16* __restrict__ b, long ldb,
+                           bf16* __restrict__ o, long ldo, long P, int C) {
+  const int vpp = C >> 3;
+  const long total = P * vpp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpp) * 8;
+    const long p = i / vpp;
+    const bf16x8 va = *reinterpret_cast<const bf16x8*>(a + p * lda + cv);
+    bf16x8 r = va;
+    if (b) {
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(b + p * ldb + cv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (bf16)((float)va[j] + (float)vb[j]);
+    }
+    *reinterpret_cast<bf16x8*>(o + p * ldo + cv) = r;
+  }
+}
+
+// dx = dy * silu'(x) (+ add)
+__global__ void silu_bwd_kernel(const bf16* __restrict__ dy, long lddy, const bf16* __restrict__ x, long ldx,
+                                bf16* __restrict__ dx, long lddx, long P, int C) {
+  const int vpp = C >> 3;
+  const long total = P * vpp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpp) * 8;
+    const long p = i / vpp;
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + p * lddy + cv);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + p * ldx + cv);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = (float)v[j];
+      const float sg = dm_sigmoid(z);
+      r[j] = (bf16)((float)d[j] * sg * (1.f + z * (1.f - sg)));
+    }
+    *reinterpret_cast<bf16x8*>(dx + p * lddx + cv) = r;
+  }
+}
+
+// out[b][c] (fp32) = sum_p x[b][p][c]   (bias / chan_add gradients); grid (C/8 vec groups..., B)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ldx, float* __restrict__ out,
+                                                      int rows, int C, int accumulate) {
+  // grid.x = batch index (rows per batch contiguous), block sums all rows of that batch
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tpp = C >> 3, ppi = 256 / tpp;
+  const int c0 = (tid % tpp) * 8, prow = tid / tpp;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (tid < tpp * ppi) {
+    for (int r = prow; r < rows; r += ppi) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)b * rows + r) * ldx + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int pr = 0; pr < ppi; ++pr) a += red[(pr * tpp + (c >> 3)) * 8 + (c & 7)];
+    if (accumulate) out[(long)b * C + c] += a; else out[(long)b * C + c] = a;
+  }
+}
+
+// out[c] += sum_b in[b][c]
+__global__ void batchsum_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) a += in[(long)b * C + c];
+  out[c] += a;
+}
+
+// ---------------------------------------------------------------- diffusion math (fp32 NCHW)
+__global__ void qsample_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                               const float* __restrict__ abar_t, float* __restrict__ xt, float* __restrict__ v,
+                               int B, long chw) {
+  const long nv = chw >> 2;
+  const long total = (long)B * nv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nv);
+    const float a = abar_t[b];
+    const float sa = sqrtf(a), so = sqrtf(1.f - a);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 ev = reinterpret_cast<const f32x4*>(e)[i];
+    reinterpret_cast<f32x4*>(xt)[i] = sa * xv + so * ev;
+    reinterpret_cast<f32x4*>(v)[i] = sa * ev - so * xv;
+  }
+}
+
+// loss = sum_b w[b] * sum_chw (out - v)^2 ; dout = 2 * w[b] * gscale * (out - v)
+// grid (nblk, B); partial[b*nblk + blk] holds per-block sums (deterministic second stage on host stream).
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ v,
+                                                   const float* __restrict__ w, float gscale,
+                                                   float* __restrict__ dout, float* __restrict__ partial, long chw) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long nv = chw >> 2;
+  const float wb = w[b];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 d = reinterpret_cast<const f32x4*>(out)[(long)b * nv + i] - reinterpret_cast<const f32x4*>(v)[(long)b * nv + i];
+    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    if (dout) reinterpret_cast<f32x4*>(dout)[(long)b * nv + i] = (2.f * wb * gscale) * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = wb * (red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// One fused sampler step. coef[b] = {sqrt(1-abar), sqrt(abar), 1/sqrt(alpha), beta/sqrt(1-abar), noise_std, g, clamp}
+__global__ void cfg_ddpm_step_kernel(const float* __restrict__ z, const float* __restrict__ vu,
+                                     const float* __restrict__ vc, const float* __restrict__ noise,
+                                     const float* __restrict__ coef, float* __restrict__ zo, int B, long chw) {
+  const long nv = chw >> 2;
+  const long total = (long)B * nv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nv);
+    const float* c = coef + (long)b * 8;
+    const float sig = c[0], sa = c[1], ria = c[2], bs = c[3], ns = c[4], g = c[5], cl = c[6];
+    const f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+    const f32x4 u = reinterpret_cast<const f32x4*>(vu)[i];
+    const f32x4 cv = reinterpret_cast<const f32x4*>(vc)[i];
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float vhat = u[j] + g * (cv[j] - u[j]);
+      const float eps = sig * zv[j] + sa * vhat;
+      float t = ria * (zv[j] - bs * eps);
+      r[j] = t;
+    }
+    if (ns != 0.f) {
+      const f32x4 n = reinterpret_cast<const f32x4*>(noise)[i];
+      r += ns * n;
+    }
+    if (cl != 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = fminf(fmaxf(r[j], -1.f), 1.f);
+    }
+    reinterpret_cast<f32x4*>(zo)[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------- optimizer
+// partial[blk] = sum g^2 over the block's grid-stride slice
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const long nv = n >> 2;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long i = nv << 2; i < n; ++i) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm_out[0] = sqrt(sum partial) ; norm_out[1] = clip coefficient min(1, max_norm/(norm+1e-6)) (1 if max_norm<=0)
+__global__ void finish_norm_kernel(const float* __restrict__ partial, int n, float max_norm, float pre_scale,
+                                   float* __restrict__ norm_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]) * pre_scale;
+    norm_out[0] = nrm;
+    norm_out[1] = (max_norm > 0.f) ? fminf(1.f, max_norm / (nrm + 1e-6f)) : 1.f;
+  }
+}
+
+struct AdamArgs {
+  float lr, b1, b2, eps, wd, bc1, bc2_sqrt, ema_decay, pre_scale;
+  int adamw;  // 1: decoupled decay (AdamW), 0: Adam (L2 decay folded in the gradient, wd usually 0)
+};
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, float* __restrict__ ema, const float* __restrict__ clip,
+                             long n, AdamArgs a) {
+  const float coef = (clip ? clip[1] : 1.f) * a.pre_scale;
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * coef;
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gg = gv[j];
+      if (a.adamw) pv[j] *= (1.f - a.lr * a.wd); else gg += a.wd * pv[j];
+      mv[j] = a.b1 * mv[j] + (1.f - a.b1) * gg;
+      vv[j] = a.b2 * vv[j] + (1.f - a.b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+      pv[j] -= (a.lr / a.bc1) * (mv[j] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (ema) {
+      f32x4 ev = reinterpret_cast<f32x4*>(ema)[i];
+      ev = a.ema_decay * ev + (1.f - a.ema_decay) * pv;
+      reinterpret_cast<f32x4*>(ema)[i] = ev;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, long ldy, int Cpad,
+                                        dm_stream_t stream) {
+  DM_REQUIRE(x && y && Cpad % 8 == 0 && Cpad >= C && ldy >= Cpad && ldy % 8 == 0);
+  const long total = (long)B * HW * (Cpad >> 3);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, (bf16*)y,
+                     B, C, HW, ldy, Cpad);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_nhwc_to_nchw_f32(const void* x, int x_is_f32, long ldx, float* y, int B, int C, int HW,
+                                   dm_stream_t stream) {
+  DM_REQUIRE(x && y);
+  const long total = (long)B * C * HW;
+  if (x_is_f32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const float*)x, ldx, y, B, C, HW);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                       (const bf16*)x, ldx, y, B, C, HW);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long P, int C,
+                           dm_stream_t stream) {
+  DM_REQUIRE(a && out && C % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0 && (!b || ldb % 8 == 0));
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(P * (C >> 3))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16*)a,
+                     lda, (const bf16*)b, ldb, (bf16*)out, ldo, P, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_silu_bwd_bf16(const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, long P,
+                                int C, dm_stream_t stream) {
+  DM_REQUIRE(dy && x && dx && C % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(P * (C >> 3))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     (const bf16*)dy, lddy, (const bf16*)x, ldx, (bf16*)dx, lddx, P, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, int rows_per_batch, int C,
+                              int accumulate, dm_stream_t stream) {
+  DM_REQUIRE(x && out && C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && 256 % (C / 8 > 256 ? 256 : C / 8) == 0 && C <= 256 * 8);
+  DM_REQUIRE(C / 8 <= 256);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nbatch), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out,
+                     rows_per_batch, C, accumulate);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_batchsum_f32(const float* in, float* out, int B, int C, dm_stream_t stream) {
+  DM_REQUIRE(in && out);
+  hipLaunchKernelGGL(batchsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, B, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_qsample_vtarget(const float* x, const float* e, const float* abar_t, float* x_t, float* v, int B,
+                                  long chw, dm_stream_t stream) {
+  DM_REQUIRE(x && e && abar_t && x_t && v && chw % 4 == 0);
+  hipLaunchKernelGGL(qsample_kernel, dim3(ew_grid((long)B * (chw >> 2))), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, e,
+                     abar_t, x_t, v, B, chw);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" long dm_mse_workspace_bytes(int B) { return (long)B * 32 * 4; }
+
+extern "C" int dm_mse_loss_fwd_bwd(const float* out, const float* v, const float* w, float grad_scale, float* dout,
+                                   float* loss, int B, long chw, void* workspace, long ws_bytes,
+                                   dm_stream_t stream) {
+  DM_REQUIRE(out && v && w && loss && workspace && chw % 4 == 0 && ws_bytes >= dm_mse_workspace_bytes(B));
+  hipLaunchKernelGGL(mse_kernel, dim3(32, B), dim3(256), 0, (hipStream_t)stream, out, v, w, grad_scale, dout,
+                     (float*)workspace, chw);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, B * 32,
+                     loss);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_cfg_ddpm_step(const float* z, const float* v_uncond, const float* v_cond, const float* noise,
+                                const float* coef, float* z_out, int B, long chw, dm_stream_t stream) {
+  DM_REQUIRE(z && v_uncond && v_cond && coef && z_out && chw % 4 == 0);
+  hipLaunchKernelGGL(cfg_ddpm_step_kernel, dim3(ew_grid((long)B * (chw >> 2))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     z, v_uncond, v_cond, noise, coef, z_out, B, chw);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" long dm_sqnorm_workspace_bytes(void) { return 1024 * 4; }
+
+extern "C" int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, float pre_scale, float* norm_out,
+                                     void* workspace, long ws_bytes, dm_stream_t stream) {
+  DM_REQUIRE(g && norm_out && workspace && ws_bytes >= dm_sqnorm_workspace_bytes() && n > 0);
+  DM_REQUIRE(((uintptr_t)g & 15) == 0);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, g, n, (float*)workspace);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finish_norm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, 1024,
+                     max_norm, pre_scale, norm_out);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip,
+                                 long n, float lr, float beta1, float beta2, float eps, float wd, int step,
+                                 float ema_decay, float pre_scale, int adamw, dm_stream_t stream) {
+  DM_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1);
+  AdamArgs a;
+  a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = wd;
+  a.bc1 = (float)(1.0 - pow((double)beta1, step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
+  a.ema_decay = ema_decay; a.pre_scale = pre_scale; a.adamw = adamw;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, ema, clip,
+                     n, a);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

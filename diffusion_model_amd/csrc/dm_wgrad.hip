@@ -1,0 +1,328 @@
+// Weight / bias gradient of the 3x3 convolutions, 1x1 convolutions and linears.
+//
+//   dW[co][ci][tap] += sum_pixels dy[pixel][co] * xv[pixel + tap][ci]
+//
+// is a GEMM whose reduction dimension is the PIXEL index, while both operands are stored
+// pixel-major (NHWC).  The MFMA fragments (8 consecutive k per lane) are therefore read from
+// the LDS images with the gfx950 transposing read ds_read_b64_tr_b16; the k -> pixel map is a
+// free permutation (the same for both operands), chosen so that the 8 pixels one half-wave
+// touches per read are consecutive => with a 160-byte pixel stride every read is
+// bank-conflict free.
+//
+// One workgroup (256 threads, 2 per CU) owns a 64(co) x 64(ci) x TAPS slice of dW, keeps it
+// in 144 accumulator registers per lane, and sweeps a strided subset of the spatial tiles
+// (split-K).  The input patch (with halo) is staged once per tile and re-read for all 9 taps.
+// Partials go to a per-workgroup fp32 slab in fragment order (16-byte coalesced stores); a
+// second kernel reduces the slabs in fixed order (bit-reproducible, no atomics) and
+// accumulates into the fp32 gradient in the reference's OIHW layout.  The bias gradient
+// rides along as one extra MFMA per k-step against an all-ones operand.
+//
+// Reference semantics replaced: autograd's weight/bias gradients of nn.Conv2d / nn.Linear
+// under scaled_loss.backward() (main_stl10.py:502-503).
+#include "dm_common.h"
+
+namespace {
+
+enum { WM_S1 = 0, WM_S2 = 1, WM_UP = 2, WM_GEMM = 4 };
+constexpr int DYS = 160;           // dy tile pixel stride (bytes)
+constexpr int SLAB_BIAS = 1024;    // floats
+
+struct WgradParams {
+  const bf16* x; long ldx;
+  const bf16* dy; long lddy;
+  float* slab;
+  int B, Hi, Wi, Cin, Cout, Ho, Wo;
+  int tiles_h, tiles_w, ntiles, nsplit;
+  long M;
+  int act_silu_in;
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int PW = (MODE == WM_GEMM) ? TW : ((S == 1) ? TW + 2 : 2 * TW + 1);
+  constexpr int NPIX = TH * TW;
+  constexpr int KSTEPS = NPIX / 32;
+  constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
+  static_assert(NPIX % 32 == 0 && TW % 8 == 0, "k-step = 32 pixels, 8 consecutive pixels per row segment");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sD = smem + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x, cot = blockIdx.y, cit = blockIdx.z;
+  const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+
+  f32x4 acc[TAPS][4];
+  f32x4 accb[4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (cit == 0) && (wave == 0);
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+  // per-lane pixel (within a k-step) for the two transposed reads
+  int kk0 = 16 * (g >> 1) + 4 * (g & 1) + qq;  // half 0; half 1 = +8
+  int xo[2], dq[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int kk = kk0 + 8 * h;
+    dq[h] = kk * DYS + pp * 8;
+    xo[h] = 0;  // filled per k-step (depends on row/col)
+  }
+
+  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    int b = 0, h0 = 0, w0 = 0;
+    long m0 = 0;
+    if constexpr (MODE == WM_GEMM) {
+      m0 = (long)tile * NPIX;
+    } else {
+      int t = tile;
+      const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+      const int th_i = t % p.tiles_h;
+      b = t / p.tiles_h;
+      h0 = th_i * TH; w0 = tw_i * TW;
+    }
+    const int vh0 = (MODE == WM_S2) ? 2 * h0 - 1 : h0 - 1;
+    const int vw0 = (MODE == WM_S2) ? 2 * w0 - 1 : w0 - 1;
+    __syncthreads();
+    // ---- stage x patch (64 channels of this ci tile)
+    for (int idx = tid; idx < PH * PW * 8; idx += 256) {
+      const int piece = idx & 7;
+      const int pix = idx >> 3;
+      const int pr = pix / PW, pc = pix % PW;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      bool valid;
+      long src;
+      const int ch = cit * 64 + piece * 8;
+      if constexpr (MODE == WM_GEMM) {
+        const long m = m0 + pix;
+        valid = (m < p.M) && (ch < p.Cin);
+        src = m * p.ldx + ch;
+      } else {
+        const int vh = vh0 + pr, vw = vw0 + pc;
+        int sh = vh, sw = vw;
+        if constexpr (MODE == WM_UP) {
+          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+          sh = vh >> 1; sw = vw >> 1;
+        } else {
+          valid = (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+        }
+        src = (((long)b * p.Hi + sh) * p.Wi + sw) * p.ldx + ch;
+      }
+      if (valid) {
+        v = *reinterpret_cast<const u32x4*>(p.x + src);
+        if (p.act_silu_in) {
+          bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
+          v = __builtin_bit_cast(u32x4, h);
+        }
+      }
+      *reinterpret_cast<u32x4*>(sX + (pr * XPITCH + pc) * XSTRIDE + piece * 16) = v;
+    }
+    // ---- stage dy tile (64 channels of this co tile)
+    for (int idx = tid; idx < NPIX * 8; idx += 256) {
+      const int piece = idx & 7;
+      const int q = idx >> 3;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int ch = cot * 64 + piece * 8;
+      long src;
+      bool valid = ch < p.Cout;
+      if constexpr (MODE == WM_GEMM) {
+        const long m = m0 + q;
+        valid = valid && (m < p.M);
+        src = m * p.lddy + ch;
+      } else {
+        const int r = q / TW, c = q % TW;
+        src = (((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c)) * p.lddy + ch;
+      }
+      if (valid) v = *reinterpret_cast<const u32x4*>(p.dy + src);
+      *reinterpret_cast<u32x4*>(sD + q * DYS + piece * 16) = v;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ksi = 0; ksi < KSTEPS; ++ksi) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kk = ksi * 32 + kk0 + 8 * h;
+        const int r = kk / TW, c = kk % TW;
+        xo[h] = ((S * r) * XPITCH + S * c) * XSTRIDE + wave * 32 + pp * 8;
+      }
+      bf16x8 a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        a[t] = tr_pair(sD + ksi * 32 * DYS + dq[0] + t * 32, sD + ksi * 32 * DYS + dq[1] + t * 32);
+      if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, accb[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+        const int tapoff = (kh * XPITCH + kw) * XSTRIDE;
+        const bf16x8 bv = tr_pair(sX + xo[0] + tapoff, sX + xo[1] + tapoff);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bv, acc[tap][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- write the slab (fragment order): [tap][cosub][wave][lane][4] then bias [cosub][lane][4]
+  const long slab_floats = (long)TAPS * 4 * 4 * 256 + SLAB_BIAS;
+  float* slab = p.slab + (((long)split * gridDim.y + cot) * gridDim.z + cit) * slab_floats;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<f32x4*>(slab + (((tap * 4 + t) * 4 + wave) * 64 + lane) * 4) = acc[tap][t];
+  if (do_bias) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<f32x4*>(slab + (long)TAPS * 4 * 4 * 256 + (t * 64 + lane) * 4) = accb[t];
+  }
+}
+
+// dw[(co*K + ci)*taps + tap] += sum_split slab[...]; dbias[co] += ...
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                    float* __restrict__ dbias, int nsplit, int ncot, int ncit, int taps, int Kreal,
+                                    int Nreal) {
+  const long slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
+  const long per_tile = (long)taps * 4 * 4 * 256;
+  const long total = (long)ncot * ncit * per_tile;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long tile = i / per_tile;
+    const int e = (int)(i % per_tile);
+    const int cot = (int)(tile / ncit), cit = (int)(tile % ncit);
+    const int reg = e & 3, lane = (e >> 2) & 63, wave = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
+    const int co = cot * 64 + t * 16 + (lane >> 4) * 4 + reg;
+    const int ci = cit * 64 + wave * 16 + (lane & 15);
+    if (co >= Nreal || ci >= Kreal) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slab[(((long)sp * ncot + cot) * ncit + cit) * slab_floats + e];
+    dw[((long)co * Kreal + ci) * taps + tap] += s;
+  }
+  if (dbias) {
+    const long totalb = (long)ncot * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totalb; i += (long)gridDim.x * blockDim.x) {
+      const int cot = (int)(i / 64), cl = (int)(i % 64);
+      const int co = cot * 64 + cl;
+      if (co >= Nreal) continue;
+      const int t = cl >> 4, q = (cl & 15) >> 2, reg = cl & 3;
+      const int e = (t * 64 + q * 16) * 4 + reg;  // lane = q*16 (column 0)
+      float s = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp)
+        s += slab[(((long)sp * ncot + cot) * ncit + 0) * slab_floats + per_tile + e];
+      dbias[co] += s;
+    }
+  }
+}
+
+struct Plan { int th, tw, ntiles, nsplit, ncot, ncit; long slab_floats; };
+
+Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
+  Plan pl{};
+  pl.ncot = (Cout + 63) / 64; pl.ncit = (Cin + 63) / 64;
+  pl.slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
+  int Ho = H, Wo = W;
+  if (mode == 1) { Ho = H / 2; Wo = W / 2; }
+  if (mode == 2) { Ho = 2 * H; Wo = 2 * W; }
+  if (taps == 1) {
+    const long M = (long)B * H * W;
+    pl.th = 8; pl.tw = 16; pl.ntiles = (int)((M + 127) / 128);
+  } else if (mode == 1) {
+    pl.th = 8; pl.tw = 8; pl.ntiles = B * (Ho / 8) * (Wo / 8);
+  } else if (Wo % 16 == 0) {
+    pl.th = 8; pl.tw = 16; pl.ntiles = B * (Ho / 8) * (Wo / 16);
+  } else if (Wo % 24 == 0) {
+    pl.th = 8; pl.tw = 24; pl.ntiles = B * (Ho / 8) * (Wo / 24);
+  } else {
+    pl.th = 8; pl.tw = 8; pl.ntiles = B * (Ho / 8) * (Wo / 8);
+  }
+  int ns = 512 / (pl.ncot * pl.ncit);
+  if (ns < 1) ns = 1;
+  if (ns > pl.ntiles) ns = pl.ntiles;
+  pl.nsplit = ns;
+  return pl;
+}
+
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS>
+int launch_wgrad(const WgradParams& p, const Plan& pl, hipStream_t st) {
+  constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
+  constexpr int LDS = X_BYTES + TH * TW * DYS;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(pl.nsplit, pl.ncot, pl.ncit), dim3(256), LDS, st, p);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" long dm_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
+  const Plan pl = make_plan(B, H, W, Cin, Cout, taps, mode);
+  return (long)pl.nsplit * pl.ncot * pl.ncit * pl.slab_floats * 4 + 256;
+}
+
+extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->dy && a->dw && a->workspace);
+  DM_REQUIRE((a->taps == 9 || a->taps == 1) && a->B > 0 && a->ldx % 8 == 0 && a->lddy % 8 == 0);
+  DM_REQUIRE(a->Cin % 8 == 0 && a->Cout % 8 == 0);
+  DM_REQUIRE(a->taps == 1 || (a->mode >= 0 && a->mode <= 2 && a->Cin % 64 == 0 && a->Cout % 64 == 0));
+  DM_REQUIRE(a->ws_bytes >= dm_wgrad_workspace_bytes(a->B, a->H, a->W, a->Cin, a->Cout, a->taps, a->mode));
+  const Plan pl = make_plan(a->B, a->H, a->W, a->Cin, a->Cout, a->taps, a->mode);
+  WgradParams p{};
+  p.x = (const bf16*)a->x; p.ldx = a->ldx; p.dy = (const bf16*)a->dy; p.lddy = a->lddy;
+  p.slab = (float*)a->workspace;
+  p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+  p.Ho = a->H; p.Wo = a->W;
+  if (a->taps == 9 && a->mode == 1) { DM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0); p.Ho = a->H / 2; p.Wo = a->W / 2; }
+  if (a->taps == 9 && a->mode == 2) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
+  if (a->taps == 9) DM_REQUIRE(p.Ho % 8 == 0 && p.Wo % 8 == 0);
+  p.tiles_h = p.Ho / pl.th; p.tiles_w = p.Wo / pl.tw; p.ntiles = pl.ntiles; p.nsplit = pl.nsplit;
+  p.M = (long)a->B * a->H * a->W;
+  p.act_silu_in = a->act_silu_in;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = DM_ERR_ARG;
+  if (a->taps == 1) rc = launch_wgrad<8, 16, 1, 16, 160, WM_GEMM, 1>(p, pl, st);
+  else if (a->mode == 1) rc = launch_wgrad<8, 8, 2, 17, 144, WM_S2, 9>(p, pl, st);
+  else if (pl.tw == 16) rc = (a->mode == 0) ? launch_wgrad<8, 16, 1, 18, 160, WM_S1, 9>(p, pl, st)
+                                            : launch_wgrad<8, 16, 1, 18, 160, WM_UP, 9>(p, pl, st);
+  else if (pl.tw == 24) rc = (a->mode == 0) ? launch_wgrad<8, 24, 1, 26, 160, WM_S1, 9>(p, pl, st)
+                                            : launch_wgrad<8, 24, 1, 26, 160, WM_UP, 9>(p, pl, st);
+  else rc = (a->mode == 0) ? launch_wgrad<8, 8, 1, 10, 160, WM_S1, 9>(p, pl, st)
+                           : launch_wgrad<8, 8, 1, 10, 160, WM_UP, 9>(p, pl, st);
+  if (rc != DM_OK) return rc;
+  const int Nreal = a->n_valid > 0 ? a->n_valid : a->Cout;
+  const int Kreal = a->k_valid > 0 ? a->k_valid : a->Cin;
+  const long total = (long)pl.ncot * pl.ncit * a->taps * 4096;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
+                     pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

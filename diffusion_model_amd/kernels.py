@@ -1,0 +1,328 @@
+"""Thin torch-tensor front-ends over the C ABI (include/dm_hip.h).  No autograd here and no
+torch math: every function only validates shapes/strides on the host, then launches HIP
+kernels on the current stream.  Activations are NHWC bf16 tensors whose last dim is
+contiguous; slices along the channel dim are allowed (pixel stride = stride(-2))."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, ConvArgs, GemmArgs, WgradArgs, check
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _act(t: torch.Tensor, what: str = "activation") -> int:
+    """Validate an NHWC/[M,C] bf16 activation view; return the pixel stride."""
+    if not (t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1):
+        raise ValueError(f"{what}: need a CUDA bf16 tensor with contiguous channels")
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    n = 1
+    for i in range(t.dim() - 2, -1, -1):  # outer dims must be densely packed over ld
+        if t.shape[i] != 1 and t.stride(i) != ld * n:
+            raise ValueError(f"{what}: unsupported strides {t.stride()} for shape {tuple(t.shape)}")
+        n *= t.shape[i]
+    return ld
+
+
+def _f32(t: Optional[torch.Tensor], what: str):
+    if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{what}: need a contiguous CUDA fp32 tensor")
+    return t
+
+
+# --------------------------------------------------------------------------- workspace
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """A per-device scratch buffer that only ever grows (stable under graph replay once warm)."""
+    key = torch.device(device).index or 0
+    cur = _WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = cur
+    return cur
+
+
+def reserve_workspace(nbytes: int, device) -> None:
+    workspace(nbytes, device)
+
+
+# --------------------------------------------------------------------------- weights
+def pack_weight(w: torch.Tensor, transpose: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [N,K,3,3] / [N,K,1,1] / [N,K] -> packed bf16 shadow (uint8 buffer).  transpose=True
+    builds the data-gradient operand (roles of N and K swapped, taps flipped)."""
+    _f32(w, "weight")
+    taps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
+    n0, k0 = w.shape[0], w.shape[1]
+    N, K = (k0, n0) if transpose else (n0, k0)
+    nbytes = _lib.lib().dm_packed_weight_bytes(N, K, taps)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert out.numel() >= nbytes
+    check(_lib.lib().dm_pack_weight(_p(w), _p(out), N, K, taps, int(transpose), _stream()), "dm_pack_weight")
+    return out
+
+
+# --------------------------------------------------------------------------- conv / gemm
+def conv3x3(x, wp, cout, *, bias=None, chan_add=None, res=None, out=None, mode=0, pool2=False,
+            act_silu_in=False, drop_p=0.0, drop_seed=0, out_f32=None, n_valid=0):
+    B, H, W, Cin = x.shape
+    ldx = _act(x, "x")
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode in (2, 3) else (H, W))
+    if pool2:
+        Ho, Wo = Ho // 2, Wo // 2
+    if out is None and out_f32 is None:
+        out = torch.empty((B, Ho, Wo, cout), dtype=BF16, device=x.device)
+    a = ConvArgs()
+    a.x, a.ldx, a.w = _p(x), ldx, _p(wp)
+    a.bias, a.chan_add = _p(_f32(bias, "bias")), _p(_f32(chan_add, "chan_add"))
+    if res is not None:
+        a.res, a.ldr = _p(res), _act(res, "res")
+        assert tuple(res.shape) == (B, Ho, Wo, cout)
+    if out is not None:
+        assert tuple(out.shape[:3]) == (B, Ho, Wo) and out.shape[3] >= (n_valid or cout)
+        a.y, a.ldy = _p(out), _act(out, "out")
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and out_f32.stride(-1) == 1
+        a.yf, a.ldyf = _p(out_f32), out_f32.stride(-2)
+    a.B, a.H, a.W, a.Cin, a.Cout = B, H, W, Cin, cout
+    a.mode, a.n_valid, a.pool2, a.act_silu_in = mode, n_valid, int(pool2), int(act_silu_in)
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    check(_lib.lib().dm_conv3x3(C.byref(a), _stream()), "dm_conv3x3")
+    return out if out is not None else out_f32
+
+
+def gemm(x, wp, n, *, bias=None, chan_add=None, rows_per_batch=0, res=None, out=None, out_f32=None,
+         act_silu_in=False, n_valid=0):
+    """x: [..., K] bf16 -> [..., n]."""
+    ldx = _act(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    if out is None and out_f32 is None:
+        out = torch.empty((*x.shape[:-1], n), dtype=BF16, device=x.device)
+    a = GemmArgs()
+    a.x, a.ldx, a.w = _p(x), ldx, _p(wp)
+    a.bias, a.chan_add = _p(_f32(bias, "bias")), _p(_f32(chan_add, "chan_add"))
+    if res is not None:
+        a.res, a.ldr = _p(res), _act(res, "res")
+    if out is not None:
+        a.y, a.ldy = _p(out), _act(out, "out")
+    if out_f32 is not None:
+        a.yf, a.ldyf = _p(out_f32), out_f32.stride(-2)
+    a.M, a.K, a.N = M, K, n
+    a.rows_per_batch, a.n_valid, a.act_silu_in = rows_per_batch, n_valid, int(act_silu_in)
+    check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
+    return out if out is not None else out_f32
+
+
+def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0, k_valid=0):
+    """dw (fp32, reference layout) += dy^T * patches(x); dbias += column sums of dy."""
+    ldx, lddy = _act(x, "x"), _act(dy, "dy")
+    _f32(dw, "dw"), _f32(dbias, "dbias")
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    if taps == 9:
+        B, H, W, _ = x.shape
+    else:
+        B, H, W = 1, 1, x.numel() // Cin
+    L = _lib.lib()
+    nb = L.dm_wgrad_workspace_bytes(B, H, W, Cin, Cout, taps, mode)
+    ws = workspace(nb, x.device)
+    a = WgradArgs()
+    a.x, a.ldx, a.dy, a.lddy, a.dw, a.dbias = _p(x), ldx, _p(dy), lddy, _p(dw), _p(dbias)
+    a.B, a.H, a.W, a.Cin, a.Cout = B, H, W, Cin, Cout
+    a.taps, a.mode, a.act_silu_in, a.n_valid, a.k_valid = taps, mode, int(act_silu_in), n_valid, k_valid
+    a.workspace, a.ws_bytes = _p(ws), ws.numel()
+    check(L.dm_wgrad(C.byref(a), _stream()), "dm_wgrad")
+
+
+# --------------------------------------------------------------------------- norm
+def gn_silu_fwd(x, gamma, beta, groups, *, chan_add=None, eps=1e-5, act=True, out=None):
+    ldx = _act(x, "x")
+    Cc = x.shape[-1]
+    B = x.shape[0]
+    HW = x.numel() // (B * Cc)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = workspace(L.dm_gn_workspace_bytes(B, HW, Cc, groups), x.device)
+    check(L.dm_gn_silu_fwd(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(_f32(gamma, "gamma")),
+                           _p(_f32(beta, "beta")), _p(out), _act(out, "out"), _p(stats), B, HW, Cc, groups,
+                           eps, int(act), _p(ws), ws.numel(), _stream()), "dm_gn_silu_fwd")
+    return out, stats
+
+
+def gn_silu_bwd(x, dy, gamma, beta, stats, groups, dgamma, dbeta, *, chan_add=None, add_in=None, act=True,
+                drop_p=0.0, drop_seed=0, out=None):
+    ldx, lddy = _act(x, "x"), _act(dy, "dy")
+    Cc = x.shape[-1]
+    B = x.shape[0]
+    HW = x.numel() // (B * Cc)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    L = _lib.lib()
+    ws = workspace(L.dm_gn_workspace_bytes(B, HW, Cc, groups), x.device)
+    check(L.dm_gn_silu_bwd(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(dy), lddy, _p(gamma), _p(beta),
+                           _p(_f32(stats, "stats")), _p(add_in), 0 if add_in is None else _act(add_in, "add_in"),
+                           _p(out), _act(out, "out"), _p(_f32(dgamma, "dgamma")), _p(_f32(dbeta, "dbeta")),
+                           B, HW, Cc, groups, int(act), float(drop_p), int(drop_seed), _p(ws), ws.numel(),
+                           _stream()), "dm_gn_silu_bwd")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed):
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    hd = Cc // heads
+    a = AttnArgs()
+    a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = _p(q), _act(q, "q"), _p(k), _act(k, "k"), _p(v), _act(v, "v")
+    a.o, a.ldo, a.lse = _p(o), _act(o, "o"), _p(_f32(lse, "lse"))
+    a.B, a.heads, a.Nq, a.Nk, a.hd = B, heads, Nq, Nk, hd
+    a.scale = 1.0 / (hd ** 0.5)
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    return a
+
+
+def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0):
+    """q: [B,Nq,C], k/v: [B,Nk,C] (views into a fused qkv buffer are fine) -> (o [B,Nq,C], lse [B,heads,Nq])."""
+    B, Nq, Cc = q.shape
+    o = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device)
+    lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
+    check(_lib.lib().dm_attn_fwd(C.byref(a), _stream()), "dm_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0.0, drop_seed=0):
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    dq = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if dq is None else dq
+    dk = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dk is None else dk
+    dv = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dv is None else dv
+    delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
+    a.d_o, a.lddo = _p(d_o), _act(d_o, "d_o")
+    a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
+    a.delta = _p(delta)
+    check(_lib.lib().dm_attn_bwd(C.byref(a), _stream()), "dm_attn_bwd")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------- layout / elementwise
+def nchw_to_nhwc(x: torch.Tensor, cpad: int = 0, out=None) -> torch.Tensor:
+    B, Cc, H, W = x.shape
+    x = _f32(x.contiguous(), "x")
+    cpad = cpad or ((Cc + 7) // 8 * 8)
+    if out is None:
+        out = torch.empty((B, H, W, cpad), dtype=BF16, device=x.device)
+    check(_lib.lib().dm_nchw_f32_to_nhwc_bf16(_p(x), _p(out), B, Cc, H * W, _act(out, "out"), cpad, _stream()),
+          "dm_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: int = 0) -> torch.Tensor:
+    B, H, W, Cc = x.shape
+    channels = channels or Cc
+    assert x.stride(-1) == 1
+    out = torch.empty((B, channels, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().dm_nhwc_to_nchw_f32(_p(x), int(x.dtype == torch.float32), x.stride(-2), _p(out), B, channels,
+                                         H * W, _stream()), "dm_nhwc_to_nchw_f32")
+    return out
+
+
+def add(a, b, out=None):
+    lda = _act(a, "a")
+    if out is None:
+        out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    Cc = a.shape[-1]
+    check(_lib.lib().dm_add_bf16(_p(a), lda, _p(b), 0 if b is None else _act(b, "b"), _p(out), _act(out, "out"),
+                                 a.numel() // Cc, Cc, _stream()), "dm_add_bf16")
+    return out
+
+
+def silu_bwd(dy, x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    Cc = x.shape[-1]
+    check(_lib.lib().dm_silu_bwd_bf16(_p(dy), _act(dy, "dy"), _p(x), _act(x, "x"), _p(out), _act(out, "out"),
+                                      x.numel() // Cc, Cc, _stream()), "dm_silu_bwd_bf16")
+    return out
+
+
+def colsum(x, out, nbatch, accumulate=False):
+    """out[b][c] (+)= sum over the batch's rows of x (x: [nbatch*rows, C] view)."""
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc // nbatch
+    check(_lib.lib().dm_colsum_bf16(_p(x), _act(x, "x"), _p(_f32(out, "out")), nbatch, rows, Cc, int(accumulate),
+                                    _stream()), "dm_colsum_bf16")
+    return out
+
+
+def batchsum(inp, out):
+    B, Cc = inp.shape
+    check(_lib.lib().dm_batchsum_f32(_p(_f32(inp, "in")), _p(_f32(out, "out")), B, Cc, _stream()), "dm_batchsum_f32")
+
+
+# --------------------------------------------------------------------------- diffusion math
+def qsample_vtarget(x, e, abar_t):
+    B = x.shape[0]
+    chw = x.numel() // B
+    xt, v = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().dm_qsample_vtarget(_p(_f32(x, "x")), _p(_f32(e, "e")), _p(_f32(abar_t, "abar_t")), _p(xt), _p(v),
+                                        B, chw, _stream()), "dm_qsample_vtarget")
+    return xt, v
+
+
+def mse_loss_fwd_bwd(out, v, w, grad_scale=1.0, want_grad=True):
+    """loss = sum_b w[b] * sum (out-v)^2 ; dout = 2 w[b] grad_scale (out-v). Returns (loss[1], dout)."""
+    B = out.shape[0]
+    chw = out.numel() // B
+    L = _lib.lib()
+    ws = workspace(L.dm_mse_workspace_bytes(B), out.device)
+    loss = torch.empty(1, dtype=torch.float32, device=out.device)
+    dout = torch.empty_like(out) if want_grad else None
+    check(L.dm_mse_loss_fwd_bwd(_p(_f32(out, "out")), _p(_f32(v, "v")), _p(_f32(w, "w")), float(grad_scale), _p(dout),
+                                _p(loss), B, chw, _p(ws), ws.numel(), _stream()), "dm_mse_loss_fwd_bwd")
+    return loss, dout
+
+
+def cfg_ddpm_step(z, v_u, v_c, noise, coef, out=None):
+    B = z.shape[0]
+    chw = z.numel() // B
+    if out is None:
+        out = torch.empty_like(z)
+    check(_lib.lib().dm_cfg_ddpm_step(_p(_f32(z, "z")), _p(_f32(v_u, "v_u")), _p(_f32(v_c, "v_c")),
+                                      _p(_f32(noise, "noise")), _p(_f32(coef, "coef")), _p(out), B, chw, _stream()),
+          "dm_cfg_ddpm_step")
+    return out
+
+
+def grad_norm_clipcoef(g, max_norm, pre_scale=1.0, out=None):
+    L = _lib.lib()
+    ws = workspace(L.dm_sqnorm_workspace_bytes(), g.device)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=g.device)
+    check(L.dm_grad_norm_clipcoef(_p(_f32(g, "g")), g.numel(), float(max_norm), float(pre_scale), _p(out), _p(ws),
+                                  ws.numel(), _stream()), "dm_grad_norm_clipcoef")
+    return out
+
+
+def adamw_ema_step(p, g, m, v, ema, clip, *, lr, beta1, beta2, eps, wd, step, ema_decay, pre_scale=1.0, adamw=True):
+    check(_lib.lib().dm_adamw_ema_step(_p(_f32(p, "p")), _p(_f32(g, "g")), _p(_f32(m, "m")), _p(_f32(v, "v")),
+                                       _p(_f32(ema, "ema")), _p(clip), p.numel(), float(lr), float(beta1),
+                                       float(beta2), float(eps), float(wd), int(step), float(ema_decay),
+                                       float(pre_scale), int(adamw), _stream()), "dm_adamw_ema_step")

@@ -1,0 +1,189 @@
+/* dm_hip.h - C ABI of libdm_hip.so, the MI355X (gfx950) kernel library under
+ * diffusion_model_amd.
+ *
+ * The reference (barebucan/Diffusion_model) has NO native / FFI boundary: its hot path is
+ * torch.nn modules composed in unet.py plus ~60 lines of schedule / sampler / loss arithmetic.
+ * Every entry point below therefore cites the reference *Python* statement whose ATen work it
+ * replaces (file:line into the reference checkout).  The Python host side
+ * (the diffusion_model_amd Python package) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted.
+ *   - activations: NHWC bf16, addressed as [pixel][channel] with an explicit pixel stride
+ *     (ld*, in elements) so slices of a concat buffer can be produced / consumed in place.
+ *   - weights: fp32 master in the reference layout (OIHW / [out,in]); kernels consume a bf16
+ *     shadow packed by dm_pack_weight.
+ *   - return 0 (DM_OK) or a negative error code; never throws; no allocation; no implicit
+ *     synchronisation; stream-ordered on `stream` (a hipStream_t passed as void*).
+ */
+#ifndef DM_HIP_H
+#define DM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dm_stream_t;
+
+#define DM_OK 0
+#define DM_ERR_ARG (-1)
+#define DM_ERR_LAUNCH (-2)
+
+/* ABI version / arch string ("gfx950"). */
+int dm_abi_version(void);
+const char* dm_target_arch(void);
+
+/* ------------------------------------------------------------------ weights */
+/* Bytes of the packed bf16 shadow of an [N][K][taps] weight (N padded to 16, K to 64). */
+long dm_packed_weight_bytes(int N, int K, int taps);
+/* Pack fp32 weights into MFMA-fragment order.  taps = 9 (3x3) or 1 (1x1 / Linear).
+ * transpose = 0: forward operand from W[N][K][kh][kw];
+ * transpose = 1: data-gradient operand: W is [K][N][kh][kw], taps are flipped (2-kh, 2-kw).
+ * Replaces: the implicit weight reads of nn.Conv2d / nn.Linear (unet.py:74-75,79,113-114,
+ * 160-163,225,234,261,317-320,333-335). */
+int dm_pack_weight(const float* w, void* dst, int N, int K, int taps, int transpose, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ convolution / GEMM */
+typedef struct dm_conv_args {
+  const void* x; long ldx;        /* input NHWC bf16 [B,H,W,Cin], pixel stride ldx */
+  const void* w;                  /* packed weights (dm_pack_weight, taps=9) */
+  const float* bias;              /* [Cout] fp32 or NULL */
+  const float* chan_add;          /* [B,Cout] fp32 added per (sample, channel) (time-embedding) or NULL */
+  const void* res; long ldr;      /* bf16 residual added to the output or NULL */
+  void* y; long ldy;              /* bf16 output or NULL */
+  float* yf; long ldyf;           /* fp32 output or NULL */
+  int B, H, W, Cin, Cout;         /* H,W = INPUT spatial size */
+  int mode;                       /* 0: 3x3 s1 p1; 1: 3x3 s2 p1; 2: nearest-x2 then 3x3 s1 p1;
+                                     3: zero-insert-x2 then 3x3 s1 p1 (data-gradient of mode 1) */
+  int n_valid;                    /* store only the first n_valid output channels (0 = all) */
+  int pool2;                      /* sum 2x2 output pixels into one (data-gradient of mode 2) */
+  int act_silu_in;                /* apply SiLU to the input while staging */
+  float drop_p;                   /* dropout on (conv+bias+chan_add) before the residual add */
+  unsigned long long drop_seed;
+} dm_conv_args;
+/* Implicit-GEMM 3x3 convolution on bf16 MFMA, LDS-staged input halo.
+ * Replaces: nn.Conv2d 3x3 (unet.py:74-75,234,317-319), F.interpolate(nearest x2)+conv
+ * (unet.py:227-229), the `h + time_emb_proj` add (unet.py:101-102), nn.Dropout
+ * (unet.py:105), the ResBlock / UnetLayer residual adds (unet.py:108,274) and, with
+ * transposed+flipped weights, the autograd data-gradient of the same convolutions. */
+int dm_conv3x3(const dm_conv_args* args, dm_stream_t stream);
+
+typedef struct dm_gemm_args {
+  const void* x; long ldx;        /* [M,K] bf16 */
+  const void* w;                  /* packed weights (taps=1) */
+  const float* bias; const float* chan_add;
+  const void* res; long ldr;
+  void* y; long ldy;
+  float* yf; long ldyf;
+  long M; int K, N;
+  int rows_per_batch;             /* chan_add row = m / rows_per_batch */
+  int n_valid; int act_silu_in;
+} dm_gemm_args;
+/* Y[M,N] = X[M,K] W[N,K]^T (+bias)(+chan_add)(+res).  Replaces nn.Conv2d 1x1 and nn.Linear
+ * (unet.py:79,113-114,160-163,261,320,87-90,333-335) and their data-gradients. */
+int dm_gemm(const dm_gemm_args* args, dm_stream_t stream);
+
+typedef struct dm_wgrad_args {
+  const void* x; long ldx;        /* forward input NHWC bf16 [B,H,W,Cin] ([M,K] for taps=1) */
+  const void* dy; long lddy;      /* output gradient NHWC bf16 [B,Ho,Wo,Cout] ([M,N]) */
+  float* dw;                      /* fp32 gradient in the REFERENCE layout [Cout][Cin][kh][kw]; accumulated (+=) */
+  float* dbias;                   /* [Cout] fp32 accumulated (+=) or NULL */
+  int B, H, W, Cin, Cout;         /* H,W = forward INPUT size; for taps=1: B*H*W = M rows */
+  int taps;                       /* 9 or 1 */
+  int mode;                       /* as dm_conv_args.mode (0,1,2) */
+  int act_silu_in;                /* forward applied SiLU to x while staging */
+  int n_valid, k_valid;           /* real Cout / Cin to write into dw (0 = all) */
+  void* workspace; long ws_bytes; /* >= dm_wgrad_workspace_bytes */
+} dm_wgrad_args;
+long dm_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode);
+/* Weight (and bias) gradient of the convolutions / linears above: split-K MFMA with
+ * transposed LDS reads, deterministic two-stage reduction.  Replaces autograd's
+ * conv/linear weight-gradient for scaled_loss.backward() (main_stl10.py:502-503). */
+int dm_wgrad(const dm_wgrad_args* args, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ GroupNorm + SiLU */
+long dm_gn_workspace_bytes(int B, int HW, int C, int G);
+/* y = act(GroupNorm(x + chan_add)) ; stats[b][g] = {mean, rstd} saved for the backward.
+ * Replaces nn.GroupNorm(8,C) + nn.SiLU (+ the time-embedding add) (unet.py:77-78,94,101-102,106). */
+int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
+                   void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
+                   void* workspace, long ws_bytes, dm_stream_t stream);
+/* dx = d/dx of the above (+ add_in), optional dropout mask (the mask dm_conv3x3 applied to x);
+ * dgamma/dbeta accumulated (+=). */
+int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
+                   const float* gamma, const float* beta, const float* stats, const void* add_in, long ldadd,
+                   void* dx, long lddx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int act_silu,
+                   float drop_p, unsigned long long drop_seed, void* workspace, long ws_bytes,
+                   dm_stream_t stream);
+
+/* ------------------------------------------------------------------ attention */
+typedef struct dm_attn_args {
+  const void* q; long ldq;        /* [B, Nq, heads*hd] bf16, token stride ldq */
+  const void* k; long ldk;        /* [B, Nk, heads*hd] */
+  const void* v; long ldv;
+  void* o; long ldo;              /* [B, Nq, heads*hd] */
+  float* lse;                     /* [B, heads, Nq] fp32 log-sum-exp (natural log of sum exp(scale*s)) */
+  const void* d_o; long lddo;     /* backward only */
+  void* dq; long lddq; void* dk; long lddk; void* dv; long lddv;
+  float* delta;                   /* [B, heads, Nq] fp32 scratch (backward) */
+  int B, heads, Nq, Nk, hd;
+  float scale;                    /* 1/sqrt(hd) */
+  float drop_p; unsigned long long drop_seed;
+} dm_attn_args;
+/* Flash-style fused softmax(QK^T*scale)V on bf16 MFMA, online softmax, no N x N matrix in
+ * memory.  Replaces F.scaled_dot_product_attention for self- and cross-attention
+ * (unet.py:119-126,136,165-172,214). */
+int dm_attn_fwd(const dm_attn_args* args, dm_stream_t stream);
+int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ layout / elementwise */
+/* NCHW fp32 -> NHWC bf16, channels zero-padded to Cpad (UNET.forward entry, unet.py:344). */
+int dm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, long ldy, int Cpad,
+                             dm_stream_t stream);
+/* NHWC (bf16 or fp32) -> NCHW fp32 (UNET.forward exit, unet.py:356). */
+int dm_nhwc_to_nchw_f32(const void* x, int x_is_f32, long ldx, float* y, int B, int C, int HW,
+                        dm_stream_t stream);
+/* out = a (+ b): residual add / strided copy into a concat slice (unet.py:274,355). */
+int dm_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long P, int C,
+                dm_stream_t stream);
+/* dx = dy * silu'(x): backward of the head's nn.SiLU (unet.py:356). */
+int dm_silu_bwd_bf16(const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, long P, int C,
+                     dm_stream_t stream);
+/* out[b][c] (=|+=) sum over the batch's rows of x[row][c]  (bias / time-projection gradients). */
+int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, int rows_per_batch, int C, int accumulate,
+                   dm_stream_t stream);
+/* out[c] += sum_b in[b][c]. */
+int dm_batchsum_f32(const float* in, float* out, int B, int C, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ diffusion math (fp32) */
+/* x_t = sqrt(a) x + sqrt(1-a) e ; v = sqrt(a) e - sqrt(1-a) x   (main_stl10.py:456-465). */
+int dm_qsample_vtarget(const float* x, const float* e, const float* abar_t, float* x_t, float* v, int B,
+                       long chw, dm_stream_t stream);
+long dm_mse_workspace_bytes(int B);
+/* loss = sum_b w[b] * sum_chw (out-v)^2 ; dout = 2 w[b] grad_scale (out-v)   (main_stl10.py:477-482,502). */
+int dm_mse_loss_fwd_bwd(const float* out, const float* v, const float* w, float grad_scale, float* dout,
+                        float* loss, int B, long chw, void* workspace, long ws_bytes, dm_stream_t stream);
+/* One fused sampler step: CFG combine on v, v->eps, DDPM mean step, eta-scaled noise, optional
+ * clamp.  coef[b][8] = {sqrt(1-abar_t), sqrt(abar_t), 1/sqrt(alpha_t), beta_t/sqrt(1-abar_t),
+ * eta*sqrt(posterior_var) (0 = no noise), guidance scale, clamp flag, unused}.
+ * Replaces main_stl10.py:130-136 + visualization.py:92-109,144-152. */
+int dm_cfg_ddpm_step(const float* z, const float* v_uncond, const float* v_cond, const float* noise,
+                     const float* coef, float* z_out, int B, long chw, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer */
+long dm_sqnorm_workspace_bytes(void);
+/* norm_out[0] = pre_scale*||g||_2, norm_out[1] = min(1, max_norm/(norm+1e-6))
+ * (torch.nn.utils.clip_grad_norm_, main_stl10.py:508). */
+int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, float pre_scale, float* norm_out,
+                          void* workspace, long ws_bytes, dm_stream_t stream);
+/* Fused clip-scale + AdamW (or Adam) + EMA over a flat fp32 buffer
+ * (main_stl10.py:396,509-510; main.py:152-153,181-182). clip = norm_out of the call above or NULL. */
+int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
+                      float lr, float beta1, float beta2, float eps, float wd, int step, float ema_decay,
+                      float pre_scale, int adamw, dm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_HIP_H */

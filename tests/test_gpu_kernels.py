@@ -1,0 +1,366 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 statement of the same op on the same
+(bf16-rounded) inputs.  Tolerances: bf16-output kernels rtol 1e-2 (+1e-2*max|ref| floor, one
+bf16 ulp is 0.4-0.8 %); fp32 kernels 1e-5..1e-4 as written per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+BF = 1e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def nhwc(t):  # NCHW fp32 -> NHWC bf16
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def nchw(t):  # NHWC bf16 -> NCHW fp32
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+def q16(t):  # bf16-round in fp32
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.fixture(scope="module")
+def K():
+    from diffusion_model_amd import kernels
+    return kernels
+
+
+# ------------------------------------------------------------------ conv forward
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 32, 48, 128, 128), (2, 24, 24, 128, 256),
+                                            (2, 8, 8, 64, 128), (1, 96, 96, 64, 64)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_conv3x3_fwd(K, B, H, W, Cin, Cout, mode):
+    if mode == 1 and (H % 16 or W % 16):
+        pytest.skip("stride-2 needs 16-divisible input")
+    if mode == 2 and H >= 96:
+        pytest.skip("big")
+    x = q16(rnd(B, Cin, H, W, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd(Cout, seed=3, scale=0.1)
+    ca = rnd(B, Cout, seed=4, scale=0.1)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == 2 else x
+    ref = F.conv2d(xi, q16(w), bias, stride=2 if mode == 1 else 1, padding=1) + ca[:, :, None, None]
+    res = q16(rnd(*ref.shape, seed=5))
+    wp = K.pack_weight(w)
+    y = K.conv3x3(nhwc(x), wp, Cout, bias=bias, chan_add=ca, res=nhwc(res), mode=mode)
+    assert_close(nchw(y), ref + res, BF, f"conv mode {mode}")
+
+
+def test_conv3x3_silu_in_f32_out_and_slices(K):
+    B, H, W, Cin, Cout = 2, 16, 16, 64, 64
+    x = q16(rnd(B, Cin, H, W, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    ref = F.conv2d(q16(F.silu(x)), q16(w), None, padding=1)
+    # input read from, and output written into, channel slices of wider buffers
+    xb = torch.zeros(B, H, W, 192, dtype=torch.bfloat16, device=dev())
+    xb[..., 64:128] = nhwc(x)
+    yb = torch.full((B, H, W, 128), 7.0, dtype=torch.bfloat16, device=dev())
+    K.conv3x3(xb[..., 64:128], K.pack_weight(w), Cout, act_silu_in=True, out=yb[..., 64:128])
+    assert_close(nchw(yb[..., 64:128]), ref, BF, "slice out")
+    assert float((yb[..., :64].float() - 7.0).abs().max()) == 0.0
+    yf = torch.empty(B, H, W, Cout, dtype=torch.float32, device=dev())
+    K.conv3x3(xb[..., 64:128], K.pack_weight(w), Cout, act_silu_in=True, out_f32=yf)
+    assert_close(yf.permute(0, 3, 1, 2), ref, 2e-3, "fp32 out")
+
+
+# ------------------------------------------------------------------ conv data-gradient
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 48, 48, 128, 64), (1, 24, 24, 256, 128)])
+def test_conv3x3_dgrad_s1(K, B, H, W, Cin, Cout):
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_()
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    dy = q16(rnd(B, Cout, H, W, seed=3))
+    (ref,) = torch.autograd.grad(F.conv2d(x, q16(w), padding=1), x, dy)
+    dx = K.conv3x3(nhwc(dy), K.pack_weight(w, transpose=True), Cin, mode=0)
+    assert_close(nchw(dx), ref, BF, "dgrad s1")
+
+
+def test_conv3x3_dgrad_s2_zero_insert(K):
+    B, H, W, Cin, Cout = 2, 32, 32, 64, 64
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_()
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    dy = q16(rnd(B, Cout, H // 2, W // 2, seed=3))
+    (ref,) = torch.autograd.grad(F.conv2d(x, q16(w), stride=2, padding=1), x, dy)
+    dx = K.conv3x3(nhwc(dy), K.pack_weight(w, transpose=True), Cin, mode=3)
+    assert_close(nchw(dx), ref, BF, "dgrad s2")
+
+
+def test_conv3x3_dgrad_upsample_pool2(K):
+    B, H, W, Cin, Cout = 2, 16, 16, 128, 128
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_()
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    dy = q16(rnd(B, Cout, 2 * H, 2 * W, seed=3))
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), q16(w), padding=1)
+    (ref,) = torch.autograd.grad(y, x, dy)
+    dx = K.conv3x3(nhwc(dy), K.pack_weight(w, transpose=True), Cin, mode=0, pool2=True)
+    assert tuple(dx.shape) == (B, H, W, Cin)
+    assert_close(nchw(dx), ref, BF, "dgrad up")
+
+
+# ------------------------------------------------------------------ gemm
+@pytest.mark.parametrize("M,Kd,N", [(64, 256, 256), (1000, 64, 128), (4608, 128, 384), (300, 32, 64),
+                                    (2, 512, 64), (513, 64, 32), (700, 256, 16)])
+def test_gemm(K, M, Kd, N):
+    x = q16(rnd(M, Kd, seed=1))
+    w = rnd(N, Kd, seed=2, scale=1.0 / math.sqrt(Kd))
+    bias = rnd(N, seed=3, scale=0.1)
+    ref = x @ q16(w).t() + bias
+    y = K.gemm(x.to(torch.bfloat16), K.pack_weight(w), N, bias=bias)
+    assert_close(y.float(), ref, BF, "gemm")
+    yf = torch.empty(M, N, dtype=torch.float32, device=dev())
+    K.gemm(x.to(torch.bfloat16), K.pack_weight(w), N, bias=bias, out_f32=yf)
+    assert_close(yf, ref, 2e-3, "gemm f32 out")
+    # data-gradient operand
+    dy = q16(rnd(M, N, seed=4))
+    dx = K.gemm(dy.to(torch.bfloat16), K.pack_weight(w, transpose=True), Kd)
+    assert_close(dx.float(), dy @ q16(w), BF, "gemm dgrad")
+
+
+def test_gemm_chan_add_rows_per_batch(K):
+    B, R, Kd, N = 3, 50, 64, 64
+    x = q16(rnd(B * R, Kd, seed=1))
+    w = rnd(N, Kd, seed=2, scale=0.2)
+    ca = rnd(B, N, seed=3)
+    ref = (x @ q16(w).t()).view(B, R, N) + ca[:, None, :]
+    y = K.gemm(x.to(torch.bfloat16), K.pack_weight(w), N, chan_add=ca, rows_per_batch=R)
+    assert_close(y.float().view(B, R, N), ref, BF, "gemm chan_add")
+
+
+# ------------------------------------------------------------------ weight gradient
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(2, 16, 16, 64, 64, 0), (3, 32, 32, 128, 64, 0),
+                                                 (2, 24, 24, 128, 256, 0), (2, 32, 32, 64, 64, 1),
+                                                 (2, 16, 16, 128, 128, 2), (2, 8, 8, 64, 64, 0),
+                                                 (1, 96, 96, 64, 64, 0)])
+def test_wgrad_conv(K, B, H, W, Cin, Cout, mode):
+    x = q16(rnd(B, Cin, H, W, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).requires_grad_()
+    bias = torch.zeros(Cout, device=dev(), requires_grad=True)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if mode == 2 else x
+    y = F.conv2d(xi, w, bias, stride=2 if mode == 1 else 1, padding=1)
+    dy = q16(rnd(*y.shape, seed=3))
+    gw, gb = torch.autograd.grad(y, [w, bias], dy)
+    dw = torch.ones_like(gw)  # accumulate semantics: starts at 1
+    db = torch.ones(Cout, device=dev())
+    K.wgrad(nhwc(x), nhwc(dy), dw, db, taps=9, mode=mode)
+    assert_close(dw - 1.0, gw, 5e-3, f"wgrad mode {mode}")
+    assert_close(db - 1.0, gb, 5e-3, "bias grad")
+
+
+@pytest.mark.parametrize("M,Kd,N", [(64, 256, 256), (1000, 64, 128), (4608, 128, 384), (300, 32, 64), (2, 512, 64)])
+def test_wgrad_linear(K, M, Kd, N):
+    x = q16(rnd(M, Kd, seed=1))
+    dy = q16(rnd(M, N, seed=2))
+    dw = torch.zeros(N, Kd, device=dev())
+    db = torch.zeros(N, device=dev())
+    K.wgrad(x.to(torch.bfloat16), dy.to(torch.bfloat16), dw, db, taps=1)
+    assert_close(dw, dy.t() @ x, 5e-3, "linear wgrad")
+    assert_close(db, dy.sum(0), 5e-3, "linear bias grad")
+
+
+def test_wgrad_silu_in_and_kvalid(K):
+    B, H, W, Cout = 2, 16, 16, 64
+    x = torch.zeros(B, 64, H, W, device=dev())
+    x[:, :3] = q16(rnd(B, 3, H, W, seed=1))
+    w = rnd(Cout, 3, 3, 3, seed=2, scale=0.1).requires_grad_()
+    y = F.conv2d(q16(F.silu(x[:, :3])), w, padding=1)
+    dy = q16(rnd(*y.shape, seed=3))
+    (gw,) = torch.autograd.grad(y, w, dy)
+    dw = torch.zeros_like(gw)
+    K.wgrad(nhwc(x), nhwc(dy), dw, None, taps=9, mode=0, act_silu_in=True, k_valid=3)
+    assert_close(dw, gw, 5e-3, "wgrad k_valid")
+
+
+# ------------------------------------------------------------------ GroupNorm + SiLU
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 12, 64), (3, 24, 24, 128), (2, 16, 16, 256), (1, 96, 96, 64)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_gn_silu(K, B, H, W, C, with_add):
+    x = q16(rnd(B, C, H, W, seed=1) * 1.5 + 0.3).requires_grad_()
+    gamma = (1 + 0.1 * rnd(C, seed=2)).requires_grad_()
+    beta = (0.1 * rnd(C, seed=3)).requires_grad_()
+    ca = rnd(B, C, seed=4) if with_add else None
+    xin = x + ca[:, :, None, None] if with_add else x
+    ref = F.silu(F.group_norm(xin, 8, gamma, beta, 1e-5))
+    dy = q16(rnd(B, C, H, W, seed=5))
+    gx, gg, gb = torch.autograd.grad(ref, [x, gamma, beta], dy)
+    xq = nhwc(x.detach())
+    y, stats = K.gn_silu_fwd(xq, gamma.detach(), beta.detach(), 8, chan_add=ca)
+    assert_close(nchw(y), ref, BF, "gn fwd")
+    xg = xin.detach().view(B, 8, -1)
+    assert_close(stats[..., 0], xg.mean(-1), 1e-4, "mean", atol_frac=1e-4)
+    assert_close(stats[..., 1], torch.rsqrt(xg.var(-1, unbiased=False) + 1e-5), 1e-4, "rstd")
+    dgamma = torch.zeros(C, device=dev())
+    dbeta = torch.zeros(C, device=dev())
+    dx = K.gn_silu_bwd(xq, nhwc(dy), gamma.detach(), beta.detach(), stats, 8, dgamma, dbeta, chan_add=ca)
+    assert_close(nchw(dx), gx, BF, "gn dx")
+    assert_close(dgamma, gg, 5e-3, "dgamma")
+    assert_close(dbeta, gb, 5e-3, "dbeta")
+
+
+# ------------------------------------------------------------------ attention
+def ref_attn(q, k, v, heads):
+    B, Nq, C = q.shape
+    hd = C // heads
+    qh = q.view(B, Nq, heads, hd).transpose(1, 2)
+    kh = k.view(B, -1, heads, hd).transpose(1, 2)
+    vh = v.view(B, -1, heads, hd).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    o = torch.softmax(s, -1) @ vh
+    return o.transpose(1, 2).reshape(B, Nq, C), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,C", [(2, 576, 576, 256), (2, 64, 64, 128), (1, 2304, 2304, 128), (2, 200, 1, 64),
+                                       (2, 130, 4, 128), (1, 576, 77, 256), (2, 96, 96, 64)])
+def test_attention_fwd_bwd(K, B, Nq, Nk, C):
+    heads = 8
+    q = q16(rnd(B, Nq, C, seed=1)).requires_grad_()
+    k = q16(rnd(B, Nk, C, seed=2)).requires_grad_()
+    v = q16(rnd(B, Nk, C, seed=3)).requires_grad_()
+    ref, lse_ref = ref_attn(q, k, v, heads)
+    d_o = q16(rnd(B, Nq, C, seed=4))
+    gq, gk, gv = torch.autograd.grad(ref, [q, k, v], d_o)
+    qb, kb, vb = (t.detach().to(torch.bfloat16) for t in (q, k, v))
+    o, lse = K.attn_fwd(qb, kb, vb, heads)
+    assert_close(o.float(), ref, BF, "attn o")
+    assert_close(lse, lse_ref, 2e-3, "lse", atol_frac=2e-3)
+    dq, dk, dv = K.attn_bwd(qb, kb, vb, o, lse, d_o.to(torch.bfloat16), heads)
+    assert_close(dv.float(), gv, 1.5e-2, "dv")
+    if Nk > 1:  # with one key softmax==1 and dq, dk are identically ~0
+        assert_close(dq.float(), gq, 1.5e-2, "dq")
+        assert_close(dk.float(), gk, 1.5e-2, "dk")
+    else:
+        assert float(dq.float().abs().max()) < 1e-2 * float(gv.abs().max())
+
+
+def test_attention_fused_qkv_views(K):
+    B, N, C, heads = 2, 128, 128, 8
+    qkv = q16(rnd(B, N, 3 * C, seed=1)).to(torch.bfloat16)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ref, _ = ref_attn(q.float(), k.float(), v.float(), heads)
+    o, _ = K.attn_fwd(q, k, v, heads)
+    assert_close(o.float(), ref, BF, "attn views")
+
+
+def test_attention_dropout_consistency(K):
+    """Dropout masks come from a counter RNG; check keep-rate and that the backward uses the forward's mask
+    (dV of a one-hot d_o equals P_drop^T restricted to that column)."""
+    B, N, C, heads, p = 1, 256, 128, 8, 0.25
+    q = q16(rnd(B, N, C, seed=1)).to(torch.bfloat16)
+    k = q16(rnd(B, N, C, seed=2)).to(torch.bfloat16)
+    v = torch.ones(B, N, C, device=dev(), dtype=torch.bfloat16)
+    o, lse = K.attn_fwd(q, k, v, heads, drop_p=p, drop_seed=1234)
+    # with V == 1: o = sum_k P_drop = (kept mass)/(1-p); mean over queries ~ 1
+    assert abs(float(o.float().mean()) - 1.0) < 0.02
+    o0, _ = K.attn_fwd(q, k, v, heads, drop_p=0.0)
+    assert float((o0.float() - 1).abs().max()) < 2e-2
+    d_o = torch.ones_like(o)
+    dq, dk, dv = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=1234)
+    # sum_keys dV[key] = sum_q sum_k P_drop[q,k] = sum_q o[q]
+    assert_close(dv.float().sum(1), o.float().sum(1), 2e-2, "dropout mass")
+
+
+# ------------------------------------------------------------------ layout / elementwise
+def test_layout_and_elementwise(K):
+    x = rnd(2, 3, 16, 16, seed=1)
+    y = K.nchw_to_nhwc(x, 64)
+    assert tuple(y.shape) == (2, 16, 16, 64)
+    assert torch.equal(y[..., :3].float(), q16(x).permute(0, 2, 3, 1))
+    assert float(y[..., 3:].float().abs().max()) == 0.0
+    back = K.nhwc_to_nchw(y, 3)
+    assert torch.equal(back, q16(x))
+    f = rnd(2, 16, 16, 32, seed=2)
+    assert torch.equal(K.nhwc_to_nchw(f, 3), f[..., :3].permute(0, 3, 1, 2))
+    a = q16(rnd(2, 8, 8, 64, seed=3)).to(torch.bfloat16)
+    b = q16(rnd(2, 8, 8, 64, seed=4)).to(torch.bfloat16)
+    buf = torch.zeros(2, 8, 8, 128, dtype=torch.bfloat16, device=dev())
+    K.add(a, b, out=buf[..., 64:])
+    assert_close(buf[..., 64:].float(), a.float() + b.float(), BF, "add")
+    K.add(a, None, out=buf[..., :64])
+    assert torch.equal(buf[..., :64], a)
+    xs = a.float().requires_grad_()
+    (g,) = torch.autograd.grad(F.silu(xs), xs, b.float())
+    assert_close(K.silu_bwd(b, a).float(), g, BF, "silu bwd")
+    cs = torch.empty(2, 64, device=dev())
+    K.colsum(a, cs, 2)
+    assert_close(cs, a.float().view(2, -1, 64).sum(1), 1e-4, "colsum")
+
+
+def test_qsample_mse_and_sampler_step(K):
+    from oracle import diffusion_ref as dref
+    B = 4
+    x, e = rnd(B, 3, 96, 96, seed=1), rnd(B, 3, 96, 96, seed=2)
+    beta, alpha, abar = (t.to(dev()) for t in dref.cosine_schedule(500))
+    t = torch.tensor([0, 17, 250, 499], device=dev())
+    xt, v = K.qsample_vtarget(x, e, abar[t].contiguous())
+    rxt, rv = dref.q_sample_v_target(x, e, abar[t])
+    assert_close(xt, rxt, 1e-6, "x_t")
+    assert_close(v, rv, 1e-6, "v")
+    out = rnd(B, 3, 96, 96, seed=3).requires_grad_()
+    ref_loss = dref.v_loss(out, rv, t, 0.01)
+    (ref_g,) = torch.autograd.grad(ref_loss / 2, out)
+    w = torch.exp(-0.01 * t.float()) / (B * 3 * 96 * 96)
+    loss, dout = K.mse_loss_fwd_bwd(out.detach(), rv, w.contiguous(), grad_scale=0.5)
+    assert_close(loss, ref_loss.reshape(1), 1e-5, "loss")
+    assert_close(dout, ref_g, 1e-5, "dloss")
+    # sampler step vs the oracle at t=499, t=2, t=1 and the final clamp step
+    z, vu, vc, n = (rnd(B, 3, 96, 96, seed=s) for s in (5, 6, 7, 8))
+    bc, ac = beta.cpu(), abar.cpu()
+    for tt, g, eta in ((499, 6.0, 1.0), (2, 6.0, 1.0), (1, 6.0, 1.0), (300, 0.0, 0.5), (0, 6.0, 1.0)):
+        tt_t = torch.full((B,), tt)
+        eps = dref.cfg_eps_from_v(z.cpu(), vu.cpu(), vc.cpu(), g, ac[tt_t])
+        if tt > 0:
+            ref = dref.ddpm_step(z.cpu(), tt, eps, bc, ac, eta, n.cpu())
+        else:
+            ref = dref.final_step(z.cpu(), eps, bc, ac)
+        from diffusion_model_amd.sampler import step_coefficients
+        coef = step_coefficients(bc, ac, tt, g, eta, B, final=(tt == 0)).to(dev())
+        got = K.cfg_ddpm_step(z, vu, vc, n, coef)
+        assert_close(got.cpu(), ref, 2e-5, f"sampler step t={tt}")
+
+
+def test_adamw_clip_ema_matches_torch(K):
+    from oracle import diffusion_ref as dref
+    n = 4096 * 5 + 8
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    # torch reference: clip_grad_norm_ + AdamW + EMA, two steps
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99))
+    ema_r = p0.clone()
+    p, m, v, ema = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev()), p0.clone()
+    for step in (1, 2):
+        g = g0 * step
+        pr.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        ema_r = 0.995 * ema_r + 0.005 * pr.detach()
+        nc = K.grad_norm_clipcoef(g, 1.0)
+        K.adamw_ema_step(p, g, m, v, ema, nc, lr=5e-5, beta1=0.9, beta2=0.99, eps=1e-8, wd=1e-4, step=step,
+                         ema_decay=0.995)
+        assert_close(nc[0:1], tn.reshape(1), 1e-5, "grad norm")
+        assert_close(p, pr.detach(), 1e-6, "param", atol_frac=1e-7)
+        assert_close(ema, ema_r, 1e-6, "ema", atol_frac=1e-7)
+    # and the oracle restatement agrees with torch on CPU
+    po, mo, vo = p0.cpu().clone(), torch.zeros(n), torch.zeros(n)
+    go = [g0.cpu().clone()]
+    dref.clip_grad_norm(go, 1.0)
+    dref.adamw_step(po, go[0], mo, vo, 1, 5e-5)
+    pr2 = torch.nn.Parameter(p0.cpu().clone())
+    opt2 = torch.optim.AdamW([pr2], lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99))
+    pr2.grad = g0.cpu().clone()
+    torch.nn.utils.clip_grad_norm_([pr2], 1.0)
+    opt2.step()
+    assert_close(po, pr2.detach(), 1e-6, "oracle adamw", atol_frac=1e-7)
