@@ -65,6 +65,8 @@ _SIGS = {
     "dm_attn_bwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "dm_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "dm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "dm_add_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "dm_silu_bwd_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "dm_colsum_bf16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

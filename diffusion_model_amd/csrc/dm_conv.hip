@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
           f32x4 v = acc[mt][nt] + acc[mt + 1][nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], 1, 64);
-          if ((lane & 1) == 0) {
-            const int r = wave * MT + mt;  // even output row of the pair
+          const int r = wave * MT + mt;  // even output row of the pair
+          if ((lane & 1) == 0 && (h0 + r) < p.Ho && (w0 + (lane & 15)) < p.Wo) {
             const int oh = (h0 + r) >> 1, ow = (w0 + (lane & 15)) >> 1;
             const long pix = ((long)b * (p.Ho >> 1) + oh) * (p.Wo >> 1) + ow;
             bf16x4 o;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         bb = (int)(pix / p.rows_per_batch);
       } else {
         const int r = q / TW, c = q % TW;
+        if (h0 + r >= p.Ho || w0 + c >= p.Wo) continue;  // tile overhangs the image
         pix = ((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c);
       }
       f32x4 v = acc[mt][nt] + bias4;
@@ -375,33 +376,32 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   if (mode == 1) { p.Ho = a->H / 2; p.Wo = a->W / 2; DM_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0); }
   else if (mode == 2 || mode == 3) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
   else { p.Ho = a->H; p.Wo = a->W; }
-  DM_REQUIRE(!p.pool2 || (p.Ho % 16 == 0 && p.Wo % 16 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
+  DM_REQUIRE(!p.pool2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
   const bool wide = (a->Cout % 128 == 0);
 #define DM_GO(TH, TW, S, PITCH, STRIDE, MODE)                                          \
   do {                                                                                 \
-    p.tiles_h = p.Ho / TH; p.tiles_w = p.Wo / TW;                                      \
+    p.tiles_h = (p.Ho + TH - 1) / TH; p.tiles_w = (p.Wo + TW - 1) / TW;                \
     if (wide) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);            \
     return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
   } while (0)
-  if (mode == 1) {
-    DM_REQUIRE(p.Ho % 8 == 0 && p.Wo % 8 == 0);
-    DM_GO(8, 8, 2, 24, 144, MODE_S2);
-  }
-  if (p.Ho % 16 == 0 && p.Wo % 16 == 0) {
+  if (mode == 1) DM_GO(8, 8, 2, 24, 144, MODE_S2);
+  // tile shape = the one that covers the image with the least padded area (edge tiles are masked);
+  // ties go to the larger tile (fewer halo bytes per pixel). pool2 needs whole row pairs per wave: 16x16.
+  auto padded = [&](int th, int tw) { return (long)((p.Ho + th - 1) / th * th) * ((p.Wo + tw - 1) / tw * tw); };
+  const long a16 = padded(16, 16), a24 = padded(8, 24), a8 = padded(8, 8);
+  if (p.pool2 || (a16 <= a24 && a16 <= a8)) {
     if (mode == 0) DM_GO(16, 16, 1, 18, 160, MODE_S1);
     if (mode == 2) DM_GO(16, 16, 1, 18, 160, MODE_UP);
     DM_GO(16, 16, 1, 18, 160, MODE_ZI);
   }
-  if (p.Ho % 8 == 0 && p.Wo % 24 == 0) {
+  if (a24 <= a8) {
     if (mode == 0) DM_GO(8, 24, 1, 32, 160, MODE_S1);
     if (mode == 2) DM_GO(8, 24, 1, 32, 160, MODE_UP);
     DM_GO(8, 24, 1, 32, 160, MODE_ZI);
   }
-  if (p.Ho % 8 == 0 && p.Wo % 8 == 0) {  // generic small images (tests, MNIST 32x32 path is 16-divisible)
-    if (mode == 0) DM_GO(8, 8, 1, 10, 160, MODE_S1);
-    if (mode == 2) DM_GO(8, 8, 1, 10, 160, MODE_UP);
-    DM_GO(8, 8, 1, 10, 160, MODE_ZI);
-  }
+  if (mode == 0) DM_GO(8, 8, 1, 10, 160, MODE_S1);
+  if (mode == 2) DM_GO(8, 8, 1, 10, 160, MODE_UP);
+  DM_GO(8, 8, 1, 10, 160, MODE_ZI);
 #undef DM_GO
   return DM_ERR_ARG;
 }

@@ -70,6 +70,13 @@ __global__ void add_kernel(const bf16* __restrict__ a, long lda, const bf16* __r
   }
 }
 
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (bf16)x[i];
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+
 // dx = dy * silu'(x) (+ add)
 __global__ void silu_bwd_kernel(const bf16* __restrict__ dy, long lddy, const bf16* __restrict__ x, long ldx,
                                 bf16* __restrict__ dx, long lddx, long P, int C) {
@@ -297,6 +304,20 @@ extern "C" int dm_nhwc_to_nchw_f32(const void* x, int x_is_f32, long ldx, float*
   else
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                        (const bf16*)x, ldx, y, B, C, HW);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_cast_f32_to_bf16(const float* x, void* y, long n, dm_stream_t stream) {
+  DM_REQUIRE(x && y && n > 0);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, (bf16*)y, n);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_cast_bf16_to_f32(const void* x, float* y, long n, dm_stream_t stream) {
+  DM_REQUIRE(x && y && n > 0);
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16*)x, y, n);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

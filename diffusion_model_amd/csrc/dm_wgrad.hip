@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         src = m * p.lddy + ch;
       } else {
         const int r = q / TW, c = q % TW;
+        valid = valid && (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile overhangs the image
         src = (((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c)) * p.lddy + ch;
       }
       if (valid) v = *reinterpret_cast<const u32x4*>(p.dy + src);
@@ -246,14 +247,16 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
   if (taps == 1) {
     const long M = (long)B * H * W;
     pl.th = 8; pl.tw = 16; pl.ntiles = (int)((M + 127) / 128);
-  } else if (mode == 1) {
-    pl.th = 8; pl.tw = 8; pl.ntiles = B * (Ho / 8) * (Wo / 8);
-  } else if (Wo % 16 == 0) {
-    pl.th = 8; pl.tw = 16; pl.ntiles = B * (Ho / 8) * (Wo / 16);
-  } else if (Wo % 24 == 0) {
-    pl.th = 8; pl.tw = 24; pl.ntiles = B * (Ho / 8) * (Wo / 24);
   } else {
-    pl.th = 8; pl.tw = 8; pl.ntiles = B * (Ho / 8) * (Wo / 8);
+    auto up = [](int v, int t) { return (v + t - 1) / t; };
+    const long a16 = (long)up(Ho, 8) * 8 * up(Wo, 16) * 16, a24 = (long)up(Ho, 8) * 8 * up(Wo, 24) * 24,
+               a8 = (long)up(Ho, 8) * 8 * up(Wo, 8) * 8;
+    pl.th = 8;
+    if (mode == 1) pl.tw = 8;
+    else if (a16 <= a24 && a16 <= a8) pl.tw = 16;
+    else if (a24 <= a8) pl.tw = 24;
+    else pl.tw = 8;
+    pl.ntiles = B * up(Ho, pl.th) * up(Wo, pl.tw);
   }
   int ns = 512 / (pl.ncot * pl.ncit);
   if (ns < 1) ns = 1;
@@ -299,10 +302,9 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   p.slab = (float*)a->workspace;
   p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
   p.Ho = a->H; p.Wo = a->W;
-  if (a->taps == 9 && a->mode == 1) { DM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0); p.Ho = a->H / 2; p.Wo = a->W / 2; }
+  if (a->taps == 9 && a->mode == 1) { DM_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0); p.Ho = a->H / 2; p.Wo = a->W / 2; }
   if (a->taps == 9 && a->mode == 2) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
-  if (a->taps == 9) DM_REQUIRE(p.Ho % 8 == 0 && p.Wo % 8 == 0);
-  p.tiles_h = p.Ho / pl.th; p.tiles_w = p.Wo / pl.tw; p.ntiles = pl.ntiles; p.nsplit = pl.nsplit;
+  p.tiles_h = (p.Ho + pl.th - 1) / pl.th; p.tiles_w = (p.Wo + pl.tw - 1) / pl.tw; p.ntiles = pl.ntiles; p.nsplit = pl.nsplit;
   p.M = (long)a->B * a->H * a->W;
   p.act_silu_in = a->act_silu_in;
   hipStream_t st = (hipStream_t)stream;

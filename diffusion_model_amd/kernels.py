@@ -244,6 +244,20 @@ def nhwc_to_nchw(x: torch.Tensor, channels: int = 0) -> torch.Tensor:
     return out
 
 
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    x = _f32(x.contiguous(), "x")
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.lib().dm_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "dm_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == BF16 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().dm_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "dm_cast_bf16_to_f32")
+    return out
+
+
 def add(a, b, out=None):
     lda = _act(a, "a")
     if out is None:

@@ -1,0 +1,671 @@
+"""Drop-in for the reference's ``unet.py``: same class names, constructor signatures,
+``forward`` signatures and ``state_dict`` keys/shapes/order (reference unet.py:44-356), so a
+reference checkpoint loads with ``strict=True`` -- but every op runs in the gfx950 HIP kernels
+of libdm_hip.so (NHWC bf16 activations, fp32 master weights + packed bf16 shadows, fp32
+accumulation).  Forward AND backward are scheduled by hand (no autograd graph inside the
+network); one ``torch.autograd.Function`` per public module keeps ``loss.backward()`` working
+for callers (main_stl10.py:502-503).
+
+Parameter containers are plain ``nn.Conv2d`` / ``nn.Linear`` / ``nn.GroupNorm`` objects created
+in the reference's registration order, so ``torch.manual_seed(s); UNET(...)`` yields the
+reference's initial weights bit-for-bit; their ``forward`` is never called.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+_EPOCH = [0]
+_SEED = itertools.count(0x5EED)
+
+
+def invalidate_packed_weights() -> None:
+    """Call after updating parameters with raw kernels (no torch version bump)."""
+    _EPOCH[0] += 1
+
+
+class PW:
+    """Packed bf16 shadows (forward operand, data-gradient operand) of one conv / linear."""
+
+    def __init__(self, c: nn.Module):
+        w = c.weight
+        self.c = c
+        self.taps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
+        self.n, self.k = w.shape[0], w.shape[1]
+        self._fwd = self._bwd = None
+        self._kf = self._kb = None
+
+    def _key(self):
+        w = self.c.weight
+        return (w.data_ptr(), w._version, _EPOCH[0])
+
+    @staticmethod
+    def of(c: nn.Module) -> "PW":
+        pw = c.__dict__.get("_dm_pw")
+        if pw is None:
+            pw = PW(c)
+            c.__dict__["_dm_pw"] = pw
+        return pw
+
+    @property
+    def fwd(self):
+        key = self._key()
+        if self._kf != key:
+            self._fwd = K.pack_weight(self.c.weight.detach(), False, self._fwd)
+            self._kf = key
+        return self._fwd
+
+    @property
+    def bwd(self):
+        key = self._key()
+        if self._kb != key:
+            self._bwd = K.pack_weight(self.c.weight.detach(), True, self._bwd)
+            self._kb = key
+        return self._bwd
+
+
+class Grads:
+    """Parameter -> fp32 gradient buffer that the wgrad kernels accumulate (+=) into."""
+
+    def __init__(self, views: Optional[Dict[int, torch.Tensor]] = None):
+        self.views = views
+        self.bufs: Dict[int, torch.Tensor] = {}
+
+    def of(self, p: Optional[torch.Tensor]):
+        if p is None:
+            return None
+        if self.views is not None:
+            return self.views[id(p)]
+        g = self.bufs.get(id(p))
+        if g is None:
+            g = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+            self.bufs[id(p)] = g
+        return g
+
+    def peek(self, p):
+        return self.bufs.get(id(p)) if self.views is None else self.views.get(id(p))
+
+
+def _b(c):
+    return None if c.bias is None else c.bias.detach()
+
+
+def _nhwc_in(x: torch.Tensor, cpad: int = 0) -> torch.Tensor:
+    return K.nchw_to_nhwc(x.detach().float().contiguous(), cpad)
+
+
+class _Fn(torch.autograd.Function):
+    """Generic adapter: runs a module's hand-written forward/backward under autograd."""
+
+    @staticmethod
+    def forward(ctx, mod, n_in, *args):
+        ins = args[:n_in]
+        out, saved = mod._run_fwd(*ins)
+        ctx.mod, ctx.saved, ctx.n_in = mod, saved, n_in
+        ctx.params = args[n_in:]
+        ctx.need_in = [torch.is_tensor(a) and a.requires_grad for a in ins]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = Grads()
+        dins = ctx.mod._run_bwd(dout.contiguous(), ctx.saved, g, ctx.need_in)
+        dins = list(dins) + [None] * (ctx.n_in - len(dins))
+        pg = []
+        for p in ctx.params:
+            t = g.peek(p)
+            pg.append(t if (t is not None and p.requires_grad) else None)
+        return (None, None, *dins, *pg)
+
+
+class HipModule(nn.Module):
+    def _apply_fn(self, *ins):
+        if not ins[0].is_cuda:
+            raise RuntimeError("diffusion_model_amd runs only on an AMD GPU (HIP kernels); there is no CPU fallback")
+        return _Fn.apply(self, len(ins), *ins, *list(self.parameters()))
+
+
+# ============================================================================ building blocks
+class SinusoidalEmbeddings(nn.Module):
+    """Reference unet.py:44-66 (table built with the same torch CPU ops -> bit-identical)."""
+
+    def __init__(self, time_steps: int, embed_dim: int):
+        super().__init__()
+        pos = torch.arange(0, time_steps, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, embed_dim, 2).float() * (-math.log(10000.0) / embed_dim))
+        emb = torch.zeros(time_steps, embed_dim, requires_grad=False)
+        emb[:, 0::2] = torch.sin(pos * div)
+        emb[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer("embeddings", emb, persistent=False)
+
+    @property
+    def embedings(self):  # reference keeps this misspelt alias
+        return self.embeddings
+
+    def forward(self, t):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t, dtype=torch.long, device=self.embeddings.device)
+        else:
+            t = t.to(self.embeddings.device).long()
+        return self.embeddings[t]
+
+
+class ResBlock(HipModule):
+    """Reference unet.py:70-108."""
+
+    def __init__(self, in_channels: int, out_channels: int, time_emb_dim: int, num_groups: int,
+                 dropout_prob: float, use_film: bool = False):
+        super().__init__()
+        if use_film:
+            raise NotImplementedError("use_film=True is never used by the reference's entry points")
+        self.relu = nn.SiLU()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.dropout = nn.Dropout(dropout_prob)
+        self.norm1 = nn.GroupNorm(num_groups, in_channels)
+        self.norm2 = nn.GroupNorm(num_groups, out_channels)
+        self.skip = nn.Conv2d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
+        self.use_film = use_film
+        self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, out_channels))
+        self.cin, self.cout, self.groups, self.p = in_channels, out_channels, num_groups, dropout_prob
+
+    # temb: bf16 [B, time_emb_dim] (pre-SiLU)
+    def _fwd(self, x, temb, out=None):
+        lin = self.time_mlp[1]
+        B = x.shape[0]
+        tp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
+        K.gemm(temb, PW.of(lin).fwd, self.cout, bias=_b(lin), act_silu_in=True, out_f32=tp)
+        g1, st1 = K.gn_silu_fwd(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
+        p = self.p if self.training else 0.0
+        seed = next(_SEED) if p > 0 else 0
+        h = K.conv3x3(g1, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1), chan_add=tp, drop_p=p, drop_seed=seed)
+        g2, st2 = K.gn_silu_fwd(h, self.norm2.weight.detach(), self.norm2.bias.detach(), self.groups)
+        if isinstance(self.skip, nn.Identity):
+            sk = x
+        else:
+            sk = K.gemm(x, PW.of(self.skip).fwd, self.cout, bias=_b(self.skip))
+        y = K.conv3x3(g2, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out)
+        return y, (x, temb, g1, st1, h, g2, st2, p, seed)
+
+    def _bwd(self, dy, saved, g: Grads, dts=None, need_dx=True):
+        """Returns (dx, dts): dts = accumulated gradient wrt silu(temb), bf16 [B, temb_dim]."""
+        x, temb, g1, st1, h, g2, st2, p, seed = saved
+        B = x.shape[0]
+        lin = self.time_mlp[1]
+        d_g2 = K.conv3x3(dy, PW.of(self.conv2).bwd, self.cout)
+        K.wgrad(g2, dy, g.of(self.conv2.weight), g.of(self.conv2.bias))
+        if isinstance(self.skip, nn.Identity):
+            dsk = dy
+        else:
+            dsk = K.gemm(dy, PW.of(self.skip).bwd, self.cin)
+            K.wgrad(x, dy, g.of(self.skip.weight), g.of(self.skip.bias), taps=1)
+        dh = K.gn_silu_bwd(h, d_g2, self.norm2.weight.detach(), self.norm2.bias.detach(), st2, self.groups,
+                           g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed)
+        dtp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
+        K.colsum(dh, dtp, B)
+        K.batchsum(dtp, g.of(self.conv1.bias))
+        K.batchsum(dtp, g.of(lin.bias))
+        dtp16 = K.to_bf16(dtp)
+        K.wgrad(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
+        d_this = torch.empty((B, temb.shape[-1]), dtype=torch.float32, device=x.device)
+        K.gemm(dtp16, PW.of(lin).bwd, temb.shape[-1], out_f32=d_this)
+        if dts is None:
+            dts = d_this
+        else:  # fp32 accumulation across the ResBlocks (batchsum with one "batch" row == axpy)
+            K.batchsum(d_this.view(1, -1), dts.view(-1))
+        K.wgrad(g1, dh, g.of(self.conv1.weight), None)
+        dx = None
+        if need_dx:
+            d_g1 = K.conv3x3(dh, PW.of(self.conv1).bwd, self.cin)
+            dx = K.gn_silu_bwd(x, d_g1, self.norm1.weight.detach(), self.norm1.bias.detach(), st1, self.groups,
+                               g.of(self.norm1.weight), g.of(self.norm1.bias), add_in=dsk)
+        else:  # norm1 affine grads are still needed
+            d_g1 = K.conv3x3(dh, PW.of(self.conv1).bwd, self.cin)
+            K.gn_silu_bwd(x, d_g1, self.norm1.weight.detach(), self.norm1.bias.detach(), st1, self.groups,
+                          g.of(self.norm1.weight), g.of(self.norm1.bias), add_in=dsk)
+        return dx, dts
+
+    # ---- public NCHW fp32 interface
+    def forward(self, x, time_emb):
+        return self._apply_fn(x, time_emb)
+
+    def _run_fwd(self, x, time_emb):
+        y, saved = self._fwd(_nhwc_in(x), K.to_bf16(time_emb.detach().float().contiguous()))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        temb = saved[1]
+        dx, dts = self._bwd(_nhwc_in(dout), saved, g)
+        dtemb = K.silu_bwd(K.to_bf16(dts), temb)
+        return K.nhwc_to_nchw(dx), K.to_f32(dtemb)
+
+
+class Attention(HipModule):
+    """Reference unet.py:110-139 (self-attention over H*W tokens; no norm, no residual inside)."""
+
+    def __init__(self, C: int, num_heads: int, dropout_prob: float, use_flash_attention: bool = True):
+        super().__init__()
+        self.linear_qkv = nn.Linear(C, C * 3, bias=False)
+        self.linear_out = nn.Linear(C, C, bias=False)
+        self.dropout_prob = dropout_prob
+        self.num_heads = num_heads
+        self.use_flash_attention = use_flash_attention
+        self.C = C
+
+    def _fwd(self, x, res=None, out=None):
+        B, H, W, C = x.shape
+        tok = x.view(B, H * W, C)
+        qkv = K.gemm(tok, PW.of(self.linear_qkv).fwd, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        p = self.dropout_prob if self.training else 0.0
+        seed = next(_SEED) if p > 0 else 0
+        o, lse = K.attn_fwd(q, k, v, self.num_heads, drop_p=p, drop_seed=seed)
+        y = K.gemm(o, PW.of(self.linear_out).fwd, C, res=None if res is None else res.view(B, H * W, C),
+                   out=None if out is None else out.view(B, H * W, C))
+        return y.view(B, H, W, C), (tok, qkv, o, lse, p, seed)
+
+    def _bwd(self, dy, saved, g: Grads, add=None):
+        tok, qkv, o, lse, p, seed = saved
+        B, N, C = tok.shape
+        dyt = dy.view(B, N, C)
+        d_o = K.gemm(dyt, PW.of(self.linear_out).bwd, C)
+        K.wgrad(o, dyt, g.of(self.linear_out.weight), None, taps=1)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        K.attn_bwd(q, k, v, o, lse, d_o, self.num_heads, dq=dqkv[..., :C], dk=dqkv[..., C:2 * C],
+                   dv=dqkv[..., 2 * C:], drop_p=p, drop_seed=seed)
+        K.wgrad(tok, dqkv, g.of(self.linear_qkv.weight), None, taps=1)
+        dx = K.gemm(dqkv, PW.of(self.linear_qkv).bwd, C, res=None if add is None else add.view(B, N, C))
+        return dx.view(dy.shape)
+
+    def forward(self, x):
+        return self._apply_fn(x)
+
+    def _run_fwd(self, x):
+        y, saved = self._fwd(_nhwc_in(x))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        return (K.nhwc_to_nchw(self._bwd(_nhwc_in(dout), saved, g)),)
+
+
+class CrossAttention(HipModule):
+    """Reference unet.py:141-220 (queries from pixels, keys/values from the context tokens)."""
+
+    def __init__(self, query_dim: int, context_dim: int, num_heads: int = 8, dropout_prob: float = 0.0,
+                 use_flash_attention: bool = True):
+        super().__init__()
+        assert query_dim % num_heads == 0, "query_dim must be divisible by num_heads"
+        self.query_dim, self.context_dim, self.num_heads = query_dim, context_dim, num_heads
+        self.dropout_prob, self.use_flash_attention = dropout_prob, use_flash_attention
+        self.to_q = nn.Linear(query_dim, query_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, query_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, query_dim, bias=False)
+        self.to_out = nn.Linear(query_dim, query_dim, bias=False)
+
+    # ctx: bf16 [B, L, Dc]
+    def _fwd(self, x, ctx, res=None, out=None):
+        B, H, W, C = x.shape
+        N = H * W
+        tok = x.view(B, N, C)
+        q = K.gemm(tok, PW.of(self.to_q).fwd, C)
+        kc = K.gemm(ctx, PW.of(self.to_k).fwd, C)
+        vc = K.gemm(ctx, PW.of(self.to_v).fwd, C)
+        p = self.dropout_prob if self.training else 0.0
+        seed = next(_SEED) if p > 0 else 0
+        o, lse = K.attn_fwd(q, kc, vc, self.num_heads, drop_p=p, drop_seed=seed)
+        y = K.gemm(o, PW.of(self.to_out).fwd, C, res=None if res is None else res.view(B, N, C),
+                   out=None if out is None else out.view(B, N, C))
+        return y.view(B, H, W, C), (tok, ctx, q, kc, vc, o, lse, p, seed)
+
+    def _bwd(self, dy, saved, g: Grads, add=None, need_dctx=False):
+        tok, ctx, q, kc, vc, o, lse, p, seed = saved
+        B, N, C = tok.shape
+        dyt = dy.view(B, N, C)
+        d_o = K.gemm(dyt, PW.of(self.to_out).bwd, C)
+        K.wgrad(o, dyt, g.of(self.to_out.weight), None, taps=1)
+        dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
+        K.wgrad(tok, dq, g.of(self.to_q.weight), None, taps=1)
+        K.wgrad(ctx, dk, g.of(self.to_k.weight), None, taps=1)
+        K.wgrad(ctx, dv, g.of(self.to_v.weight), None, taps=1)
+        dx = K.gemm(dq, PW.of(self.to_q).bwd, C, res=None if add is None else add.view(B, N, C))
+        dctx = None
+        if need_dctx:
+            dctx = K.gemm(dk, PW.of(self.to_k).bwd, self.context_dim)
+            dctx = K.gemm(dv, PW.of(self.to_v).bwd, self.context_dim, res=dctx)
+        return dx.view(dy.shape), dctx
+
+    def forward(self, x, context):
+        return self._apply_fn(x, context)
+
+    def _run_fwd(self, x, context):
+        c = context.detach().float()
+        self._ctx2d = c.dim() == 2
+        if c.dim() == 2:
+            c = c.unsqueeze(1)
+        y, saved = self._fwd(_nhwc_in(x), K.to_bf16(c.contiguous()))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        dx, dctx = self._bwd(_nhwc_in(dout), saved, g, need_dctx=True)
+        dctx = K.to_f32(dctx)
+        if self._ctx2d:
+            dctx = dctx.squeeze(1)
+        return K.nhwc_to_nchw(dx), dctx
+
+
+class Upsample(HipModule):
+    """Reference unet.py:222-229: nearest x2 then conv3x3 (the x2 tensor is never materialised)."""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, kernel_size=3, padding=1)
+        self.ch = ch
+
+    def _fwd(self, x):
+        return K.conv3x3(x, PW.of(self.conv).fwd, self.ch, bias=_b(self.conv), mode=2), (x,)
+
+    def _bwd(self, dy, saved, g: Grads, add=None):
+        (x,) = saved
+        K.wgrad(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=2)
+        dx = K.conv3x3(dy, PW.of(self.conv).bwd, self.ch, pool2=True)
+        return dx if add is None else K.add(dx, add)
+
+    def forward(self, x):
+        return self._apply_fn(x)
+
+    def _run_fwd(self, x):
+        y, saved = self._fwd(_nhwc_in(x))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        return (K.nhwc_to_nchw(self._bwd(_nhwc_in(dout), saved, g)),)
+
+
+class Downsample(HipModule):
+    """Reference unet.py:231-237: conv3x3 stride 2."""
+
+    def __init__(self, ch: int):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, kernel_size=3, stride=2, padding=1)
+        self.ch = ch
+
+    def _fwd(self, x):
+        return K.conv3x3(x, PW.of(self.conv).fwd, self.ch, bias=_b(self.conv), mode=1), (x,)
+
+    def _bwd(self, dy, saved, g: Grads, add=None):
+        (x,) = saved
+        K.wgrad(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=1)
+        return K.conv3x3(dy, PW.of(self.conv).bwd, self.ch, mode=3, res=add)
+
+    def forward(self, x):
+        return self._apply_fn(x)
+
+    def _run_fwd(self, x):
+        y, saved = self._fwd(_nhwc_in(x))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        return (K.nhwc_to_nchw(self._bwd(_nhwc_in(dout), saved, g)),)
+
+
+class UnetLayer(HipModule):
+    """Reference unet.py:239-285."""
+
+    def __init__(self, upscale: bool, attention: bool, num_groups: int, dropout_prob: float, in_channels: int,
+                 out_channels: int, time_emb_dim: int, num_heads: int = 4, use_film: bool = False,
+                 use_cross_attention: bool = False, context_dim: int = None, use_flash_attention: bool = True):
+        super().__init__()
+        self.res_block = ResBlock(in_channels, out_channels, time_emb_dim, num_groups, dropout_prob, use_film)
+        if attention:
+            self.attention = Attention(out_channels, num_heads, dropout_prob, use_flash_attention=use_flash_attention)
+        if use_cross_attention and context_dim is not None:
+            self.cross_attention = CrossAttention(query_dim=out_channels, context_dim=context_dim,
+                                                  num_heads=num_heads, dropout_prob=dropout_prob,
+                                                  use_flash_attention=use_flash_attention)
+        if upscale:
+            self.upsample = Upsample(out_channels)
+            self.conv = nn.Conv2d(out_channels, out_channels // 2, kernel_size=1)
+        else:
+            self.downsample = Downsample(out_channels)
+        self.cout = out_channels
+
+    def _fwd(self, x, temb, ctx, skip_out=None, y_out=None):
+        """Down layers write the pre-downsample tensor (the skip) into ``skip_out``; up layers write
+        their output into ``y_out`` (both are channel slices of the decoder's concat buffer)."""
+        has_a = hasattr(self, "attention")
+        has_c = hasattr(self, "cross_attention") and ctx is not None
+        up = hasattr(self, "upsample")
+        r, s_res = self.res_block._fwd(x, temb)
+        dst = None if up else skip_out
+        s_a = s_c = None
+        if has_a and has_c:
+            xa, s_a = self.attention._fwd(r)
+            xo, s_c = self.cross_attention._fwd(xa, ctx, res=r, out=dst)
+        elif has_a:
+            xo, s_a = self.attention._fwd(r, res=r, out=dst)
+        elif has_c:
+            xo, s_c = self.cross_attention._fwd(r, ctx, res=r, out=dst)
+        else:
+            xo = K.add(r, r, out=dst)
+        if up:
+            u, s_u = self.upsample._fwd(xo)
+            B, H2, W2, C = u.shape
+            y = K.gemm(u.view(B, H2 * W2, C), PW.of(self.conv).fwd, C // 2, bias=_b(self.conv),
+                       out=None if y_out is None else y_out.view(B, H2 * W2, C // 2))
+            y = y.view(B, H2, W2, C // 2)
+            return y, xo, (s_res, s_a, s_c, s_u, u)
+        y, s_d = self.downsample._fwd(xo)
+        return y, xo, (s_res, s_a, s_c, s_d, None)
+
+    def _bwd(self, dy, d_skip, saved, g: Grads, dts=None, need_dx=True):
+        s_res, s_a, s_c, s_ud, u = saved
+        if hasattr(self, "upsample"):
+            B, H2, W2, Ch = dy.shape
+            dyt = dy.view(B, H2 * W2, Ch)
+            du = K.gemm(dyt, PW.of(self.conv).bwd, 2 * Ch)
+            K.wgrad(u.view(B, H2 * W2, 2 * Ch), dyt, g.of(self.conv.weight), g.of(self.conv.bias), taps=1)
+            dxo = self.upsample._bwd(du.view(B, H2, W2, 2 * Ch), s_ud, g)
+        else:
+            dxo = self.downsample._bwd(dy, s_ud, g, add=d_skip)
+        # xo = attn_path(r) + r
+        if s_a is not None and s_c is not None:
+            dxa, _ = self.cross_attention._bwd(dxo, s_c, g)
+            dr = self.attention._bwd(dxa, s_a, g, add=dxo)
+        elif s_a is not None:
+            dr = self.attention._bwd(dxo, s_a, g, add=dxo)
+        elif s_c is not None:
+            dr, _ = self.cross_attention._bwd(dxo, s_c, g, add=dxo)
+        else:
+            dr = K.add(dxo, dxo)
+        return self.res_block._bwd(dr, s_res, g, dts, need_dx)
+
+
+# ============================================================================ the network
+class UNET(HipModule):
+    """Reference unet.py:287-356."""
+
+    def __init__(self, Channels: List = [64, 64, 128, 256, 128], Upscales: List = [False, False, True, True],
+                 Attentions: List = [False, True, True, False], num_groups: int = 8, dropout_prob: float = 0.1,
+                 num_heads: int = 8, time_steps: int = 1000, input_channels: int = 1, output_channels: int = 1,
+                 label_embedding: bool = True, use_film: bool = False, use_cross_attention: bool = True,
+                 context_dim: int = None, use_flash_attention: bool = True):
+        super().__init__()
+        time_emb_dim = 256
+        self.num_layers = len(Channels) - 1
+        for i in range(self.num_layers):
+            layer = UnetLayer(Upscales[i], Attentions[i], num_groups, dropout_prob, Channels[i], Channels[i + 1],
+                              time_emb_dim, num_heads, use_film, use_cross_attention=use_cross_attention,
+                              context_dim=context_dim, use_flash_attention=use_flash_attention)
+            setattr(self, f"Layer{i + 1}", layer)
+        out_channels = (Channels[-1] // 2) + Channels[1]
+        self.input_conv = nn.Conv2d(input_channels, Channels[0], kernel_size=3, padding=1)
+        self.late_conv1 = nn.Conv2d(out_channels, out_channels // 2, kernel_size=3, padding=1)
+        self.late_conv2 = nn.Conv2d(out_channels // 2, out_channels // 2, kernel_size=3, padding=1)
+        self.output_conv = nn.Conv2d(out_channels // 2, output_channels, kernel_size=1)
+        self.relu = nn.SiLU()
+        nn.init.zeros_(self.output_conv.weight)
+        if self.output_conv.bias is not None:
+            nn.init.zeros_(self.output_conv.bias)
+        self.time_embeddings = SinusoidalEmbeddings(time_steps, time_emb_dim)
+        self.time_mlp = nn.Sequential(nn.Linear(time_emb_dim, time_emb_dim), nn.SiLU(),
+                                      nn.Linear(time_emb_dim, time_emb_dim))
+        self.Channels, self.Upscales = list(Channels), list(Upscales)
+        self.cin, self.cout_img, self.temb_dim = input_channels, output_channels, time_emb_dim
+        half = self.num_layers // 2
+        for c in Channels:
+            if c % 64:
+                raise ValueError("the gfx950 conv kernels tile channels by 64: every entry of Channels must be a multiple of 64")
+        if any(Upscales[:half]) or not all(Upscales[half:]):
+            raise ValueError("encoder layers must downsample and decoder layers upsample (as in every reference config)")
+
+    def layers(self):
+        return [getattr(self, f"Layer{i + 1}") for i in range(self.num_layers)]
+
+    # ------------------------------------------------------------------ hand-scheduled forward
+    def _fwd(self, x, t, context):
+        B, Cin, H, W = x.shape
+        dev_ = x.device
+        e16 = K.to_bf16(self.time_embeddings(t).contiguous())
+        if e16.shape[0] != B:
+            if e16.shape[0] != 1:
+                raise ValueError("t must have one entry per sample (or a single entry)")
+            e16 = e16.expand(B, -1).contiguous()
+        l0, l2 = self.time_mlp[0], self.time_mlp[2]
+        h1 = K.gemm(e16, PW.of(l0).fwd, self.temb_dim, bias=_b(l0))
+        temb = K.gemm(h1, PW.of(l2).fwd, self.temb_dim, bias=_b(l2), act_silu_in=True)
+        ctx = None
+        if context is not None and torch.is_floating_point(context):
+            c = context.detach().float()
+            if c.dim() == 2:
+                c = c.unsqueeze(1)
+            ctx = K.to_bf16(c.contiguous())
+        x0 = K.nchw_to_nhwc(x.detach().float().contiguous(), (Cin + 63) // 64 * 64)
+        a = K.conv3x3(x0, PW.of(self.input_conv).fwd, self.Channels[0], bias=_b(self.input_conv))
+        L, half = self.num_layers, self.num_layers // 2
+        cats: List[Optional[torch.Tensor]] = [None] * L
+        saved_layers = []
+        for i in range(half):
+            j = L - 1 - i
+            c_dec, c_skip = self.Channels[j + 1] // 2, self.Channels[i + 1]
+            cats[j] = torch.empty((B, a.shape[1], a.shape[2], c_dec + c_skip), dtype=BF16, device=dev_)
+            a, _, s = self.layers()[i]._fwd(a, temb, ctx, skip_out=cats[j][..., c_dec:])
+            saved_layers.append(s)
+        for i in range(half, L):
+            c_dec = self.Channels[i + 1] // 2
+            _, _, s = self.layers()[i]._fwd(a, temb, ctx, y_out=cats[i][..., :c_dec])
+            a = cats[i]
+            saved_layers.append(s)
+        cat = a
+        Bc, Hc, Wc, Cc = cat.shape
+        a1 = K.conv3x3(cat, PW.of(self.late_conv1).fwd, Cc // 2, bias=_b(self.late_conv1))
+        a2 = K.conv3x3(a1, PW.of(self.late_conv2).fwd, Cc // 2, bias=_b(self.late_conv2), act_silu_in=True)
+        npad = (self.cout_img + 15) // 16 * 16
+        of = torch.empty((Bc, Hc, Wc, npad), dtype=torch.float32, device=dev_)
+        K.gemm(a2.view(Bc, Hc * Wc, Cc // 2), PW.of(self.output_conv).fwd, npad, bias=_pad_bias(self.output_conv, npad),
+               act_silu_in=True, out_f32=of.view(Bc, Hc * Wc, npad), n_valid=self.cout_img)
+        y = K.nhwc_to_nchw(of, self.cout_img)
+        return y, (x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2)
+
+    # ------------------------------------------------------------------ hand-scheduled backward
+    def _bwd(self, dout, saved, g: Grads, need_dx=False):
+        x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2 = saved
+        L, half = self.num_layers, self.num_layers // 2
+        cat = cats[L - 1]
+        B, Hc, Wc, Cc = cat.shape
+        Ch = Cc // 2
+        M = Hc * Wc
+        dy16 = K.nchw_to_nhwc(dout.detach().float().contiguous(), 16 if self.cout_img <= 16 else 0)
+        kp = dy16.shape[-1]
+        oc = self.output_conv
+        K.wgrad(a2.view(B, M, Ch), dy16.view(B, M, kp), g.of(oc.weight).view(self.cout_img, Ch), g.of(oc.bias), taps=1,
+                act_silu_in=True, n_valid=self.cout_img)
+        d_s2 = K.gemm(dy16.view(B, M, kp), PW.of(oc).bwd, Ch)
+        d_a2 = K.silu_bwd(d_s2.view(B, Hc, Wc, Ch), a2)
+        K.wgrad(a1, d_a2, g.of(self.late_conv2.weight), g.of(self.late_conv2.bias), act_silu_in=True)
+        d_s1 = K.conv3x3(d_a2, PW.of(self.late_conv2).bwd, Ch)
+        d_a1 = K.silu_bwd(d_s1, a1)
+        K.wgrad(cat, d_a1, g.of(self.late_conv1.weight), g.of(self.late_conv1.bias))
+        d_cat = K.conv3x3(d_a1, PW.of(self.late_conv1).bwd, Cc)
+        dts = None
+        d_skips: List[Optional[torch.Tensor]] = [None] * L
+        da = None
+        for i in range(L - 1, half - 1, -1):
+            c_dec = self.Channels[i + 1] // 2
+            d_skips[L - 1 - i] = d_cat[..., c_dec:]
+            da, dts = self.layers()[i]._bwd(d_cat[..., :c_dec], None, saved_layers[i], g, dts)
+            d_cat = da  # gradient wrt this decoder layer's input = previous concat buffer (or encoder output)
+        for i in range(half - 1, -1, -1):
+            last = (i == 0)
+            da, dts = self.layers()[i]._bwd(da, d_skips[i], saved_layers[i], g, dts, need_dx=True)
+        # input conv
+        ic = self.input_conv
+        K.wgrad(x0, da, g.of(ic.weight), g.of(ic.bias), k_valid=self.cin)
+        dx = None
+        if need_dx:
+            # rare path (callers normally do not differentiate wrt the image): the data-gradient
+            # operand needs its N (= input channels) padded to the 64-wide tile, so pad on the host
+            wpad = torch.zeros((ic.weight.shape[0], x0.shape[-1], 3, 3), dtype=torch.float32, device=da.device)
+            wpad[:, : self.cin] = ic.weight.detach()
+            dxp = K.conv3x3(da, K.pack_weight(wpad, True), x0.shape[-1])
+            dx = K.nhwc_to_nchw(dxp, self.cin)
+        # time MLP
+        l0, l2 = self.time_mlp[0], self.time_mlp[2]
+        dtemb = K.silu_bwd(K.to_bf16(dts), temb)
+        K.wgrad(h1, dtemb, g.of(l2.weight), g.of(l2.bias), taps=1, act_silu_in=True)
+        dsh1 = K.gemm(dtemb, PW.of(l2).bwd, self.temb_dim)
+        dh1 = K.silu_bwd(dsh1, h1)
+        K.wgrad(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
+        return dx
+
+    # ------------------------------------------------------------------ public API
+    def forward(self, x, t, context=None):
+        if not x.is_cuda:
+            raise RuntimeError("diffusion_model_amd.UNET runs only on an AMD GPU (HIP kernels); no CPU fallback")
+        if context is not None and not torch.is_floating_point(context):
+            if any(hasattr(l, "cross_attention") for l in self.layers()):
+                raise TypeError("integer labels as context are only accepted when no cross-attention exists "
+                                "(reference unet.py:271 would feed them to nn.Linear and fail)")
+            context = None  # legacy label tensor: ignored, as in the reference (main.py:177)
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t, dtype=torch.long)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _UNetFn.apply(self, x, t, context, *list(self.parameters()))
+        y, _ = self._fwd(x, t, context)
+        return y
+
+
+def _pad_bias(c: nn.Module, npad: int):
+    if c.bias is None:
+        return None
+    b = torch.zeros(npad, dtype=torch.float32, device=c.bias.device)
+    b[: c.bias.numel()] = c.bias.detach()
+    return b
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, t, context, *params):
+        y, saved = mod._fwd(x, t, context)
+        ctx.mod, ctx.saved, ctx.params = mod, saved, params
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = Grads()
+        dx = ctx.mod._bwd(dout.contiguous(), ctx.saved, g, need_dx=ctx.need_dx)
+        pg = []
+        for p in ctx.params:
+            t = g.peek(p)
+            pg.append(t if p.requires_grad else None)
+        return (None, dx, None, None, *pg)

@@ -144,6 +144,9 @@ int dm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, long
 /* NHWC (bf16 or fp32) -> NCHW fp32 (UNET.forward exit, unet.py:356). */
 int dm_nhwc_to_nchw_f32(const void* x, int x_is_f32, long ldx, float* y, int B, int C, int HW,
                         dm_stream_t stream);
+/* dtype casts of small contiguous buffers (time-embedding rows, per-(b,c) sums). */
+int dm_cast_f32_to_bf16(const float* x, void* y, long n, dm_stream_t stream);
+int dm_cast_bf16_to_f32(const void* x, float* y, long n, dm_stream_t stream);
 /* out = a (+ b): residual add / strided copy into a concat slice (unet.py:274,355). */
 int dm_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long P, int C,
                 dm_stream_t stream);

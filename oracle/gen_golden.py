@@ -34,11 +34,16 @@ os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 
 
-def load_cf(module: torch.nn.Module, gain: float = 1.0):
+def load_cf(module: torch.nn.Module, gain: float = 1.0, seed: int = 1234):
+    """Module-level fixtures use the well-conditioned seeded fill (oracle.unet_ref.seeded_fill)."""
     shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
-    sd = oref.closed_form_fill(shapes, gain)
+    sd = oref.seeded_fill(shapes, seed, gain)
     module.load_state_dict(sd, strict=True)
     return sd
+
+
+def _rt(shape, seed, scale=1.0):
+    return oref.seeded_tensor(shape, int(seed * 10) + 100, scale)
 
 
 def grads_of(module, out, G, inputs):
@@ -61,9 +66,9 @@ def save(name, **arrs):
 def gen_resblock(tag, cin, cout, hw, B=2):
     m = ref_unet.ResBlock(cin, cout, 256, 8, 0.0).eval()
     load_cf(m)
-    x = oref.det_tensor((B, cin, hw, hw), 0.3).requires_grad_()
-    te = oref.det_tensor((B, 256), 1.1).requires_grad_()
-    G = oref.det_tensor((B, cout, hw, hw), 2.2)
+    x = _rt((B, cin, hw, hw), 0.3).requires_grad_()
+    te = _rt((B, 256), 1.1).requires_grad_()
+    G = _rt((B, cout, hw, hw), 2.2)
     y = m(x, te)
     (gx, gte), gp = grads_of(m, y, G, [x, te])
     save(f"resblock_{tag}", x=x, temb=te, G=G, y=y, gx=gx, gtemb=gte,
@@ -72,9 +77,9 @@ def gen_resblock(tag, cin, cout, hw, B=2):
 
 def gen_attention(tag, C, hw, B=2):
     m = ref_unet.Attention(C, 8, 0.0).eval()
-    load_cf(m, gain=2.0)
-    x = oref.det_tensor((B, C, hw, hw), 0.7).requires_grad_()
-    G = oref.det_tensor((B, C, hw, hw), 2.9)
+    load_cf(m, gain=1.0)
+    x = _rt((B, C, hw, hw), 0.7).requires_grad_()
+    G = _rt((B, C, hw, hw), 2.9)
     y = m(x)
     (gx,), gp = grads_of(m, y, G, [x])
     save(f"attention_{tag}", x=x, G=G, y=y, gx=gx, **{"g." + k: v for k, v in gp.items()})
@@ -82,10 +87,10 @@ def gen_attention(tag, C, hw, B=2):
 
 def gen_cross(tag, C, hw, L, B=2, D=512):
     m = ref_unet.CrossAttention(C, D, 8, 0.0).eval()
-    load_cf(m, gain=2.0)
-    x = oref.det_tensor((B, C, hw, hw), 0.9).requires_grad_()
-    ctx = oref.det_tensor((B, D) if L == 0 else (B, L, D), 1.7).requires_grad_()
-    G = oref.det_tensor((B, C, hw, hw), 3.1)
+    load_cf(m, gain=1.0)
+    x = _rt((B, C, hw, hw), 0.9).requires_grad_()
+    ctx = _rt((B, D) if L == 0 else (B, L, D), 1.7).requires_grad_()
+    G = _rt((B, C, hw, hw), 3.1)
     y = m(x, ctx)
     (gx, gc), gp = grads_of(m, y, G, [x, ctx])
     save(f"cross_{tag}", x=x, ctx=ctx, G=G, y=y, gx=gx, gctx=gc,
@@ -96,9 +101,9 @@ def gen_updown():
     for name, cls in (("upsample", ref_unet.Upsample), ("downsample", ref_unet.Downsample)):
         m = cls(64).eval()
         load_cf(m)
-        x = oref.det_tensor((2, 64, 16, 16), 0.2).requires_grad_()
+        x = _rt((2, 64, 16, 16), 0.2).requires_grad_()
         y = m(x)
-        G = oref.det_tensor(tuple(y.shape), 1.9)
+        G = _rt(tuple(y.shape), 1.9)
         (gx,), gp = grads_of(m, y, G, [x])
         save(name, x=x, G=G, y=y, gx=gx, **{"g." + k: v for k, v in gp.items()})
 
@@ -107,9 +112,9 @@ def gen_gn_silu():
     gn = torch.nn.GroupNorm(8, 64).eval()
     load_cf(gn)
     act = torch.nn.SiLU()
-    x = (oref.det_tensor((2, 64, 12, 12), 0.4) * 1.5 + 0.25).requires_grad_()
+    x = (_rt((2, 64, 12, 12), 0.4) * 1.5 + 0.25).requires_grad_()
     y = act(gn(x))
-    G = oref.det_tensor(tuple(y.shape), 0.6)
+    G = _rt(tuple(y.shape), 0.6)
     (gx,), gp = grads_of(gn, y, G, [x])
     save("gn_silu", x=x, G=G, y=y, gx=gx, **{"g." + k: v for k, v in gp.items()})
 
@@ -157,6 +162,40 @@ def gen_unet(tag, spec_kw, B, hw, ctx_mode, full_grads=()):
     save(f"unet_{tag}", **arr)
 
 
+def gen_unet_init(tag, spec_kw, B, hw, ctx_mode):
+    """Realistic weights: the reference's own default init under torch.manual_seed(0), with a
+    non-zero output_conv (N(0,0.05^2), generator seed 1).  The weights are NOT stored (16.7 MB):
+    the GPU test rebuilds them with the same seed through the drop-in module (same registration
+    order => same RNG stream) and verifies the per-tensor norms stored here."""
+    torch.manual_seed(0)
+    m = ref_unet.UNET(**spec_kw).eval()
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        m.output_conv.weight.copy_(torch.randn(m.output_conv.weight.shape, generator=gen) * 0.05)
+    cin = spec_kw.get("input_channels", 1)
+    x = torch.randn(B, cin, hw, hw, generator=gen).requires_grad_()
+    t = torch.tensor([(37 * i + 11) % 500 for i in range(B)])
+    ctx = None
+    if ctx_mode == "clip":
+        tab = np.load("/root/reference/artifacts/clip/clip_text_emb_stl10_vitb32.npz",
+                      allow_pickle=False)["embeddings_norm"].astype(np.float32)
+        ctx = torch.from_numpy(tab)[torch.tensor([(3 * i + 1) % 11 for i in range(B)])]
+    elif ctx_mode == "labels":
+        ctx = torch.tensor([i % 11 for i in range(B)])
+    G = torch.randn(B, spec_kw.get("output_channels", 1), hw, hw, generator=gen)
+    y = m(x, t, ctx)
+    (gx,), gp = grads_of(m, y, G, [x])
+    arr = dict(x=x, t=t, G=G, y=y, gx=gx, **grad_digest(gp))
+    arr.update({"wn." + k: torch.linalg.vector_norm(v).reshape(1) for k, v in m.state_dict().items()})
+    big = sorted(((v.numel(), k) for k, v in gp.items() if v is not None))
+    for _, k in big[:40]:  # every small tensor in full (norm/bias/time-MLP rows), big ones via digest
+        if gp[k].numel() <= 70000:
+            arr["gf." + k] = gp[k]
+    if ctx is not None:
+        arr["ctx"] = ctx
+    save(f"unet_{tag}", **arr)
+
+
 def gen_tables():
     # sinusoid rows from the real reference class
     se = ref_unet.SinusoidalEmbeddings(1000, 256)
@@ -180,7 +219,7 @@ def main():
     torch.manual_seed(0)
     gen_tables()
     gen_gn_silu()
-    gen_resblock("id64", 64, 64, 12)
+    gen_resblock("id64", 64, 64, 16)
     gen_resblock("skip64_128", 64, 128, 8)
     gen_attention("c128_hd16", 128, 8)
     gen_attention("c256_hd32", 256, 6)
@@ -197,6 +236,9 @@ def main():
     gen_unet("stl10_small", stl, 2, 32, "clip")
     mn = dict(time_steps=1000, Attentions=[False] * 6, dropout_prob=0.0)
     gen_unet("mnist", mn, 2, 32, "labels")
+    gen_unet_init("stl10_init", stl, 2, 96, "clip")
+    gen_unet_init("stl10_init_noctx", stl, 2, 48, None)
+    gen_unet_init("mnist_init", mn, 4, 32, "labels")
 
 
 if __name__ == "__main__":

@@ -164,24 +164,76 @@ def det_tensor(shape, seed: float = 0.0, scale: float = 1.0) -> Tensor:
     return torch.from_numpy(v.astype(np.float32)).reshape(shape).clone()
 
 
+def seeded_fill(shapes: "Dict[str, tuple]", seed: int, gain: float = 1.0) -> Dict[str, Tensor]:
+    """Well-conditioned random fill from an explicit CPU generator (same torch build => same
+    values on the GPU box): weights N(0, gain^2/fan_in), norm weights 1+0.1 N, biases 0.05 N.
+    (The closed-form sin patterns above cancel heavily inside long dot products, which makes
+    bf16-storage pipelines look 10x worse than they are on realistic weights.)"""
+    gen = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    for name, shape in shapes.items():
+        r = torch.randn(shape, generator=gen)
+        if re.search(r"norm\d?\.weight$", name) or (name == "weight" and len(shape) == 1):
+            v = 1.0 + 0.1 * r
+        elif name.endswith("bias"):
+            v = 0.05 * r
+        else:
+            n = 1
+            for s in shape:
+                n *= s
+            v = r * (gain / math.sqrt(n // shape[0]))
+        sd[name] = v
+    return sd
+
+
+def seeded_tensor(shape, seed: int, scale: float = 1.0) -> Tensor:
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# --------------------------------------------------------------------------- bf16 noise model
+class _RoundBoth(torch.autograd.Function):
+    """Identity that rounds to bf16 in forward AND rounds the gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+EMULATE_BF16 = False  # tests flip this to estimate the rounding noise a bf16-storage pipeline must show
+
+
+def _q(x: Tensor) -> Tensor:
+    """Activation materialisation point (identity in the fp32 oracle)."""
+    return _RoundBoth.apply(x) if EMULATE_BF16 else x
+
+
+def _w(x: Tensor) -> Tensor:
+    """Weight use point: bf16 shadow of the fp32 master (forward value only; gradient stays fp32)."""
+    return x + (x.to(torch.bfloat16).float() - x).detach() if EMULATE_BF16 else x
+
+
 # --------------------------------------------------------------------------- blocks
 def _gn_silu(x: Tensor, w: Tensor, b: Tensor, groups: int) -> Tensor:
-    return F.silu(F.group_norm(x, groups, w, b, eps=1e-5))
+    return _q(F.silu(F.group_norm(x, groups, w, b, eps=1e-5)))
 
 
 def res_block(sd, p: str, x: Tensor, temb: Tensor, groups: int, drop_p: float = 0.0,
               train: bool = False) -> Tensor:
     """unet.py:92-108 (use_film=False branch)."""
     h = F.conv2d(_gn_silu(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], groups),
-                 sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
-    tp = F.linear(F.silu(temb), sd[p + "time_mlp.1.weight"], sd[p + "time_mlp.1.bias"])
+                 _w(sd[p + "conv1.weight"]), sd[p + "conv1.bias"], padding=1)
+    tp = F.linear(F.silu(temb), _w(sd[p + "time_mlp.1.weight"]), sd[p + "time_mlp.1.bias"])
     h = h + tp[:, :, None, None]
-    h = F.dropout(h, drop_p, training=train)
+    h = _q(F.dropout(h, drop_p, training=train))
     h = F.conv2d(_gn_silu(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"], groups),
-                 sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+                 _w(sd[p + "conv2.weight"]), sd[p + "conv2.bias"], padding=1)
     if (p + "skip.weight") in sd:
-        x = F.conv2d(x, sd[p + "skip.weight"], sd[p + "skip.bias"])
-    return x + h
+        x = _q(F.conv2d(x, _w(sd[p + "skip.weight"]), sd[p + "skip.bias"]))
+    return _q(x + h)
 
 
 def softmax_attention(q: Tensor, k: Tensor, v: Tensor, drop_p: float = 0.0,
@@ -198,10 +250,10 @@ def self_attention(sd, p: str, x: Tensor, heads: int, drop_p=0.0, train=False) -
     """unet.py:128-139."""
     B, C, H, W = x.shape
     tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    qkv = F.linear(tok, sd[p + "linear_qkv.weight"]).reshape(B, H * W, 3, heads, C // heads)
+    qkv = _q(F.linear(tok, _w(sd[p + "linear_qkv.weight"]))).reshape(B, H * W, 3, heads, C // heads)
     q, k, v = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
-    o = softmax_attention(q, k, v, drop_p, train).permute(0, 2, 1, 3).reshape(B, H * W, C)
-    o = F.linear(o, sd[p + "linear_out.weight"])
+    o = _q(softmax_attention(q, k, v, drop_p, train)).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    o = _q(F.linear(o, _w(sd[p + "linear_out.weight"])))
     return o.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
 
@@ -214,11 +266,12 @@ def cross_attention(sd, p: str, x: Tensor, ctx: Tensor, heads: int, drop_p=0.0,
         ctx = ctx[:, None, :]
     L = ctx.shape[1]
     d = C // heads
-    q = F.linear(tok, sd[p + "to_q.weight"]).reshape(B, H * W, heads, d).permute(0, 2, 1, 3)
-    k = F.linear(ctx, sd[p + "to_k.weight"]).reshape(B, L, heads, d).permute(0, 2, 1, 3)
-    v = F.linear(ctx, sd[p + "to_v.weight"]).reshape(B, L, heads, d).permute(0, 2, 1, 3)
-    o = softmax_attention(q, k, v, drop_p, train).permute(0, 2, 1, 3).reshape(B, H * W, C)
-    o = F.linear(o, sd[p + "to_out.weight"])
+    ctx = _q(ctx)
+    q = _q(F.linear(tok, _w(sd[p + "to_q.weight"]))).reshape(B, H * W, heads, d).permute(0, 2, 1, 3)
+    k = _q(F.linear(ctx, _w(sd[p + "to_k.weight"]))).reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    v = _q(F.linear(ctx, _w(sd[p + "to_v.weight"]))).reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    o = _q(softmax_attention(q, k, v, drop_p, train)).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    o = _q(F.linear(o, _w(sd[p + "to_out.weight"])))
     return o.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
 
 
@@ -232,15 +285,15 @@ def unet_layer(sd, spec: UNetSpec, i: int, x: Tensor, temb: Tensor, ctx, train=F
         x = self_attention(sd, p + "attention.", x, spec.num_heads, dp, train)
     if spec.has_cross() and ctx is not None:
         x = cross_attention(sd, p + "cross_attention.", x, ctx, spec.num_heads, dp, train)
-    x = x + res
+    x = _q(x + res)
     if spec.Upscales[i]:
         x = F.interpolate(x, scale_factor=2, mode="nearest")
-        x = F.conv2d(x, sd[p + "upsample.conv.weight"], sd[p + "upsample.conv.bias"], padding=1)
-        x = F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"])
+        x = _q(F.conv2d(x, _w(sd[p + "upsample.conv.weight"]), sd[p + "upsample.conv.bias"], padding=1))
+        x = _q(F.conv2d(x, _w(sd[p + "conv.weight"]), sd[p + "conv.bias"]))
         return x, x
     skip = x
-    x = F.conv2d(x, sd[p + "downsample.conv.weight"], sd[p + "downsample.conv.bias"],
-                 stride=2, padding=1)
+    x = _q(F.conv2d(x, _w(sd[p + "downsample.conv.weight"]), sd[p + "downsample.conv.bias"],
+                    stride=2, padding=1))
     return x, skip
 
 
@@ -248,9 +301,9 @@ def time_embedding(sd, spec: UNetSpec, t) -> Tensor:
     """unet.py:59-66 + 339-340."""
     tab = sinusoid_table(spec.time_steps, spec.time_emb_dim)
     t = torch.as_tensor(t, dtype=torch.long).reshape(-1)
-    e = tab[t]
-    e = F.linear(e, sd["time_mlp.0.weight"], sd["time_mlp.0.bias"])
-    return F.linear(F.silu(e), sd["time_mlp.2.weight"], sd["time_mlp.2.bias"])
+    e = _q(tab[t])
+    e = _q(F.linear(e, _w(sd["time_mlp.0.weight"]), sd["time_mlp.0.bias"]))
+    return _q(F.linear(F.silu(e), _w(sd["time_mlp.2.weight"]), sd["time_mlp.2.bias"]))
 
 
 def unet_forward(sd: Dict[str, Tensor], spec: UNetSpec, x: Tensor, t, context=None,
@@ -263,7 +316,7 @@ def unet_forward(sd: Dict[str, Tensor], spec: UNetSpec, x: Tensor, t, context=No
             raise TypeError("integer context with cross-attention enabled")
         context = None
     skips = []
-    x = F.conv2d(x, sd["input_conv.weight"], sd["input_conv.bias"], padding=1)
+    x = _q(F.conv2d(_q(x), _w(sd["input_conv.weight"]), sd["input_conv.bias"], padding=1))
     half = spec.num_layers // 2
     for i in range(half):
         x, r = unet_layer(sd, spec, i, x, temb, context, train)
@@ -271,6 +324,6 @@ def unet_forward(sd: Dict[str, Tensor], spec: UNetSpec, x: Tensor, t, context=No
     for i in range(half, spec.num_layers):
         y, _ = unet_layer(sd, spec, i, x, temb, context, train)
         x = torch.cat((y, skips.pop()), dim=1)
-    x = F.silu(F.conv2d(x, sd["late_conv1.weight"], sd["late_conv1.bias"], padding=1))
-    x = F.silu(F.conv2d(x, sd["late_conv2.weight"], sd["late_conv2.bias"], padding=1))
-    return F.conv2d(x, sd["output_conv.weight"], sd["output_conv.bias"])
+    x = _q(F.silu(_q(F.conv2d(x, _w(sd["late_conv1.weight"]), sd["late_conv1.bias"], padding=1))))
+    x = _q(F.silu(_q(F.conv2d(x, _w(sd["late_conv2.weight"]), sd["late_conv2.bias"], padding=1))))
+    return F.conv2d(x, _w(sd["output_conv.weight"]), sd["output_conv.bias"])

@@ -43,10 +43,10 @@ def K():
 
 # ------------------------------------------------------------------ conv forward
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 32, 48, 128, 128), (2, 24, 24, 128, 256),
-                                            (2, 8, 8, 64, 128), (1, 96, 96, 64, 64)])
+                                            (2, 8, 8, 64, 128), (1, 96, 96, 64, 64), (2, 12, 12, 64, 64), (1, 20, 36, 64, 128)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_conv3x3_fwd(K, B, H, W, Cin, Cout, mode):
-    if mode == 1 and (H % 16 or W % 16):
+    if mode == 1 and (H % 2 or W % 2):
         pytest.skip("stride-2 needs 16-divisible input")
     if mode == 2 and H >= 96:
         pytest.skip("big")
@@ -80,7 +80,7 @@ def test_conv3x3_silu_in_f32_out_and_slices(K):
 
 
 # ------------------------------------------------------------------ conv data-gradient
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 48, 48, 128, 64), (1, 24, 24, 256, 128)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 48, 48, 128, 64), (1, 24, 24, 256, 128), (2, 12, 12, 64, 64), (1, 20, 36, 128, 64)])
 def test_conv3x3_dgrad_s1(K, B, H, W, Cin, Cout):
     x = rnd(B, Cin, H, W, seed=1).requires_grad_()
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
@@ -145,7 +145,7 @@ def test_gemm_chan_add_rows_per_batch(K):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(2, 16, 16, 64, 64, 0), (3, 32, 32, 128, 64, 0),
                                                  (2, 24, 24, 128, 256, 0), (2, 32, 32, 64, 64, 1),
                                                  (2, 16, 16, 128, 128, 2), (2, 8, 8, 64, 64, 0),
-                                                 (1, 96, 96, 64, 64, 0)])
+                                                 (1, 96, 96, 64, 64, 0), (2, 12, 12, 64, 64, 0), (1, 20, 36, 64, 128, 0), (2, 12, 12, 64, 64, 2), (2, 24, 24, 64, 64, 1)])
 def test_wgrad_conv(K, B, H, W, Cin, Cout, mode):
     x = q16(rnd(B, Cin, H, W, seed=1))
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).requires_grad_()

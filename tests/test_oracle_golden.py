@@ -13,7 +13,7 @@ FP32 = 1e-4
 
 
 def _sd(shapes, gain=1.0):
-    return oref.closed_form_fill(shapes, gain)
+    return oref.seeded_fill(shapes, 1234, gain)
 
 
 def test_schedule_bit_exact_and_kats():
@@ -89,7 +89,7 @@ def test_self_attention(tag, C):
     g = load_golden(f"attention_{tag}")
     order = ["linear_qkv.weight", "linear_out.weight"]
     sd = {k: v.requires_grad_() for k, v in
-          _sd({"linear_qkv.weight": (3 * C, C), "linear_out.weight": (C, C)}, 2.0).items()}
+          _sd({"linear_qkv.weight": (3 * C, C), "linear_out.weight": (C, C)}, 1.0).items()}
     x = g["x"].clone().requires_grad_()
     y = oref.self_attention(sd, "", x, 8)
     assert_close(y, g["y"], FP32, "y")
@@ -105,7 +105,7 @@ def test_cross_attention(tag, C):
     order = ["to_q.weight", "to_k.weight", "to_v.weight", "to_out.weight"]
     sd = {k: v.requires_grad_() for k, v in _sd(
         {"to_q.weight": (C, C), "to_k.weight": (C, 512), "to_v.weight": (C, 512),
-         "to_out.weight": (C, C)}, 2.0).items()}
+         "to_out.weight": (C, C)}, 1.0).items()}
     x = g["x"].clone().requires_grad_()
     ctx = g["ctx"].clone().requires_grad_()
     y = oref.cross_attention(sd, "", x, ctx, 8)
