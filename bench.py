@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Headline benchmark: STL10 96x96 v-prediction UNet training (B=64 per GPU, accumulation 2, AdamW +
+clip + EMA, dropout 0.1, low-t weighting -- the reference's shipped train() configuration,
+main_stl10.py:352-516) on synthetic data, plus the 500-step CFG sampling rate.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE OPTIMIZER STEP = 2 micro-batches of 64 images per GPU (forward + backward each), the
+gradient exchange (N>1), clip + AdamW + EMA and the repack of the bf16 weight shadows.  Rank 0
+prints one JSON line (contract in the task statement)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16 = 2.5e15       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+TRAIN_FLOP_PER_IMG = 55.7e9   # algorithmic fwd+dgrad+wgrad FLOPs / image (reference op count)
+FWD_FLOP_PER_IMG = 18.08e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--sample-images", type=int, default=88, help="CFG samples per GPU (88 x 8 GPUs = 11 labels x 64 = configs[3];  0 = skip)")
+    ap.add_argument("--sample-steps", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_batch(B, rank, dev, table, scheduler):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.clamp(torch.randn(B, 3, 96, 96, generator=g) * 0.5, -1, 1).to(dev)
+    labels = torch.randint(0, 10, (B,), generator=g)
+    labels[torch.rand(B, generator=g) < 0.2] = 10
+    t = torch.randint(0, 500, (B,), generator=g).to(dev)
+    e = torch.randn(B, 3, 96, 96, generator=g).to(dev)
+    ctx = table[labels].to(dev).contiguous()
+    return x, ctx, t, e
+
+
+def build_model(dropout, dev):
+    from diffusion_model_amd import utils
+    from diffusion_model_amd.unet import UNET
+    table = utils._load_clip_context_table()
+    torch.manual_seed(0)
+    model = UNET(time_steps=1000, input_channels=3, output_channels=3, dropout_prob=dropout, context_dim=512)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():  # zero-init output_conv would make every other gradient exactly 0
+        model.output_conv.weight.copy_(torch.randn(model.output_conv.weight.shape, generator=gen) * 0.05)
+    return model.to(dev), table
+
+
+def time_dominant_kernel(B, dev, reps=20):
+    """Live HIP-event timing of the dominant kernel family: nearest-x2 + conv3x3 (the two largest convs,
+    36 % of forward FLOPs), on the stream it is launched on.  Returns (avg_seconds, flops_per_launch)."""
+    from diffusion_model_amd import kernels as K
+    shapes = [(48, 128, 128), (24, 256, 256)]  # (input H=W, Cin, Cout): L4.upsample.conv, L3.upsample.conv
+    tot, flops = 0.0, 0.0
+    for H, cin, cout in shapes:
+        x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
+        wp = K.pack_weight(w)
+        bias = torch.zeros(cout, device=dev)
+        y = torch.empty(B, 2 * H, 2 * H, cout, dtype=torch.bfloat16, device=dev)
+        for _ in range(3):
+            K.conv3x3(x, wp, cout, bias=bias, mode=2, out=y)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            K.conv3x3(x, wp, cout, bias=bias, mode=2, out=y)
+        e.record()
+        e.synchronize()
+        tot += s.elapsed_time(e) * 1e-3 / reps
+        flops += 2.0 * B * (2 * H) * (2 * H) * cout * cin * 9
+    return tot / len(shapes), flops / len(shapes)
+
+
+def cpu_baseline():
+    """The oracle (CPU fp32 restatement of the reference) timed on this box's host cores: config C1
+    (B=8, 96x96, CLIP context, v-loss with low-t weighting, clip 1.0, AdamW), dropout 0, 1 warm-up +
+    3 timed optimizer steps (about 10-20 s of CPU work).  A reported baseline, not a target."""
+    from oracle import diffusion_ref as dref
+    from oracle import unet_ref as oref
+    import numpy as np
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    spec = oref.UNetSpec(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0)
+    g = torch.Generator().manual_seed(0)
+    sd = {k: v.requires_grad_() for k, v in oref.seeded_fill(oref.param_shapes(spec), 0, 1.0).items()}
+    names = list(sd)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+    tab = np.load(os.path.join(ROOT, "diffusion_model_amd", "artifacts", "clip", "clip_text_emb_stl10_vitb32.npz"),
+                  allow_pickle=False)["embeddings_norm"].astype(np.float32)
+    beta, alpha, abar = dref.cosine_schedule(500)
+    B = 8
+
+    def step(i):
+        x = torch.clamp(torch.randn(B, 3, 96, 96, generator=g) * 0.5, -1, 1)
+        t = torch.randint(0, 500, (B,), generator=g)
+        e = torch.randn(B, 3, 96, 96, generator=g)
+        ctx = torch.from_numpy(tab)[torch.randint(0, 11, (B,), generator=g)]
+        xt, v = dref.q_sample_v_target(x, e, abar[t])
+        out = oref.unet_forward(sd, spec, xt, t, ctx)
+        loss = dref.v_loss(out, v, t, 0.01)
+        grads = list(torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True))
+        grads = [gg if gg is not None else torch.zeros_like(sd[k]) for gg, k in zip(grads, names)]
+        dref.clip_grad_norm(grads, 1.0)
+        with torch.no_grad():
+            for k, gg in zip(names, grads):
+                dref.adamw_step(sd[k], gg, m[k], vv[k], i + 1, 5e-5)
+
+    step(0)
+    t0 = time.perf_counter()
+    n = 3
+    for i in range(n):
+        step(i + 1)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"{n} optimizer steps of B={B} 96x96 fp32 (fwd+bwd+clip+AdamW, dropout 0, no accumulation) "
+                      f"after 1 warm-up; torch {torch.__version__} CPU, {threads} threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diffusion_model_amd.ema import ModelEmaV2
+    from diffusion_model_amd.sampler import CFGSampler
+    from diffusion_model_amd.trainer import Trainer
+    from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+
+    model, table = build_model(a.dropout, dev)
+    model.train()
+    sched = DDPM_beta_t_cosine_scheduler(500)
+    ema = ModelEmaV2(model, decay=0.995)
+    tr = Trainer(model, sched, lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99), clip=1.0, ema_decay=0.995,
+                 accum=2, total_steps=100 * 79, start_step=20 * 40, low_t_weight=0.01, ema=ema,
+                 distributed=world > 1)
+    batches = [synth_batch(a.batch, rank * 2 + i, dev, table, sched) for i in range(2)]
+
+    def opt_step():
+        loss = None
+        for b in batches:
+            loss = tr.micro_step(*b)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        opt_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = opt_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    imgs = a.steps * 2 * a.batch * world
+    value = imgs / dt
+    final_loss = float(loss.item())
+
+    # ---------------- sampling leg (batch-sharded, no collective in the loop)
+    sampling = None
+    if a.sample_images > 0:
+        S = a.sample_images
+        smp = CFGSampler(ema.module, sched, table, uncond_id=10)
+        gz = torch.Generator(device="cpu").manual_seed(42 + rank)
+        z = torch.randn(S, 3, 96, 96, generator=gz).to(dev)
+        labels = (torch.arange(S) + rank * S) % 11
+        smp.sample(z[:S], labels, 6.0, 1.0, num_time_steps=500, t_stop=497)  # warm-up: 3 steps
+        barrier()
+        t1 = time.perf_counter()
+        x0 = smp.sample(z, labels, 6.0, 1.0, num_time_steps=a.sample_steps)
+        barrier()
+        ds = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([ds], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ds = float(tt.item())
+        ok = bool(torch.isfinite(x0).all().item())
+        sampling = {"metric": "500-step CFG sample img/s", "value": S * world / ds, "unit": "img/s",
+                    "images": S * world, "steps": a.sample_steps, "seconds": ds, "guidance": 6.0, "eta": 1.0,
+                    "cond_uncond_batched": True, "finite": ok,
+                    "mfma_frac_algorithmic": (S * world / ds) * FWD_FLOP_PER_IMG * 2 * a.sample_steps / (PEAK_BF16 * world)}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    out = {
+        "metric": "train img/s (node) STL10 96x96 UNet B=64/GPU", "value": value, "unit": "img/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic", "final_loss": final_loss,
+        "config": {"workload": "configs[1]: main_stl10 UNet v-pred train step 96x96x3, B=64/GPU bf16, AdamW+EMA+clip, "
+                               "accumulation 2 (step = 1 optimizer step = 128 img/GPU), CLIP ctx, low-t weighting",
+                   "global_batch": 2 * a.batch * world, "micro_batch": a.batch, "dropout": a.dropout,
+                   "parallelism": f"dp{world}", "weights": "reference init (seed 0), output_conv N(0,0.05^2)"},
+        "step_mfma_frac_algorithmic": value * TRAIN_FLOP_PER_IMG / (PEAK_BF16 * world),
+    }
+    if sampling:
+        out["sampling"] = sampling
+    if not a.no_roofline:
+        sec, fl = time_dominant_kernel(a.batch, dev)
+        out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                           "frac": fl / sec / PEAK_BF16, "traffic": None,
+                           "kernel": "conv_mfma_kernel<16,16,1,18,160,8,MODE_UP> (nearest-x2 + conv3x3, B=%d)" % a.batch,
+                           "avg_launch_us": sec * 1e6, "flop_per_launch": fl}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

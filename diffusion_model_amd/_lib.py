@@ -5,6 +5,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libdm_hip.so is dlopen'ed: the PyTorch-ROCm wheel bundles its own
+# libamdhip64; loading ours first would bring a second HIP runtime (the system one) into the process,
+# and kernels launched through it see "no ROCm-capable device".  With torch first, our DT_NEEDED
+# libamdhip64 resolves to the already-loaded runtime, so streams and device pointers are shared.
+import torch  # noqa: F401  (side effect: loads the HIP runtime the whole process will use)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdm_hip.so")
 
@@ -49,6 +55,8 @@ class AttnArgs(C.Structure):
 _SIGS = {
     "dm_abi_version": (c_int, []),
     "dm_target_arch": (C.c_char_p, []),
+    "dm_last_hip_error": (C.c_char_p, []),
+    "dm_note_hip_error": (None, [c_int]),
     "dm_packed_weight_bytes": (c_long, [c_int, c_int, c_int]),
     "dm_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dm_conv3x3": (c_int, [C.POINTER(ConvArgs), c_void_p]),
@@ -111,5 +119,7 @@ def lib():
 
 def check(code: int, what: str) -> None:
     if code != 0:
-        raise DmError(f"{what} failed with code {code} "
-                      f"({'bad argument' if code == -1 else 'launch error' if code == -2 else 'unknown'})")
+        detail = "bad argument" if code == -1 else "unknown"
+        if code == -2:
+            detail = "launch error: " + (lib().dm_last_hip_error() or b"?").decode()
+        raise DmError(f"{what} failed with code {code} ({detail})")

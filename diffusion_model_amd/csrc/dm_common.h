@@ -15,13 +15,22 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+extern "C" void dm_note_hip_error(int code);  // dm_api.hip: remembered for dm_last_hip_error()
 #define DM_LAUNCH_CHECK()                                   \
   do {                                                      \
-    if (hipGetLastError() != hipSuccess) return DM_ERR_LAUNCH; \
+    const hipError_t dm_e_ = hipGetLastError();             \
+    if (dm_e_ != hipSuccess) {                              \
+      dm_note_hip_error((int)dm_e_);                        \
+      return DM_ERR_LAUNCH;                                 \
+    }                                                       \
   } while (0)
 
+// Every entry point validates its arguments with DM_REQUIRE before its first launch; the macro also
+// drains the thread's sticky "last error" (the host framework's own benign failures, e.g.
+// hipErrorNotReady from an event query, would otherwise be mis-reported by DM_LAUNCH_CHECK).
 #define DM_REQUIRE(cond)            \
   do {                              \
+    (void)hipGetLastError();        \
     if (!(cond)) return DM_ERR_ARG; \
   } while (0)
 

@@ -6,6 +6,8 @@ coefficients are computed on the host in fp32 with the same torch ops as the ref
 (so they are bit-identical), the per-element work is ONE kernel (dm_cfg_ddpm_step)."""
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 
@@ -31,3 +33,92 @@ def step_coefficients(beta: torch.Tensor, abar: torch.Tensor, t: int, guidance, 
     coef = row[None, :].repeat(batch, 1)
     coef[:, 5] = torch.as_tensor(guidance, dtype=torch.float32)
     return coef.contiguous()
+
+
+def _ddpm_step(z: torch.Tensor, t: int, predicted_noise: torch.Tensor, scheduler, eta: float) -> torch.Tensor:
+    """Reference visualization.py:92-109 (torch statement kept for callers that use the reference's
+    ``predict_eps_fn`` callback contract; the fast path below fuses all of it into one kernel)."""
+    alpha_bar_t = scheduler.alpha_t[t]
+    beta_t = scheduler.beta_t[t]
+    alpha_t = 1.0 - beta_t
+    alpha_bar_prev = scheduler.alpha_t[t - 1] if t > 0 else torch.tensor(1.0, device=z.device)
+    z = (1.0 / torch.sqrt(alpha_t)) * (z - (beta_t / torch.sqrt(1.0 - alpha_bar_t)) * predicted_noise)
+    if t > 1 and eta > 0.0:
+        noise = torch.randn_like(z)
+        posterior_var = beta_t * (1.0 - alpha_bar_prev) / (1.0 - alpha_bar_t)
+        z = z + eta * torch.sqrt(posterior_var) * noise
+    return z
+
+
+def run_reverse_process(model, scheduler, z_init, labels, guidance_scale, eta, num_time_steps, predict_eps_fn,
+                        capture_timesteps=None):
+    """Reference visualization.py:112-152, same signature and return value."""
+    with torch.no_grad():
+        model.eval()
+        capture_timesteps = capture_timesteps or []
+        snapshots = {}
+        z = z_init.clone()
+        for t in reversed(range(1, num_time_steps)):
+            t_tensor = torch.tensor([t], device=z.device)
+            eps = predict_eps_fn(model, scheduler, z, t_tensor, labels, guidance_scale)
+            z = _ddpm_step(z, t, eps, scheduler, eta)
+            if t in capture_timesteps:
+                snapshots[t] = torch.clamp(z, -1, 1)
+        t_tensor = torch.tensor([0], device=z.device)
+        eps = predict_eps_fn(model, scheduler, z, t_tensor, labels, guidance_scale)
+        alpha_0 = 1.0 - scheduler.beta_t[0]
+        x0 = (1.0 / torch.sqrt(alpha_0)) * (z - (scheduler.beta_t[0] / torch.sqrt(1.0 - scheduler.alpha_t[0])) * eps)
+        snapshots[0] = torch.clamp(x0, -1, 1)
+        return torch.clamp(x0, -1, 1), snapshots
+
+
+class CFGSampler:
+    """Batched 500-step CFG sampler: per step ONE UNet forward over [uncond; cond] (batch 2S) and ONE
+    fused elementwise kernel (CFG combine, v->eps, DDPM mean, eta noise, final clamp).  No collective
+    in the loop: under data parallelism every rank samples its own shard of the labels."""
+
+    def __init__(self, model, scheduler, context_table: torch.Tensor, uncond_id: int):
+        self.model, self.sched = model, scheduler
+        self.table = context_table
+        self.uncond_id = uncond_id
+
+    @torch.no_grad()
+    def sample(self, z: torch.Tensor, labels: torch.Tensor, guidance_scale=6.0, eta: float = 1.0,
+               num_time_steps: Optional[int] = None, generator: Optional[torch.Generator] = None,
+               noises=None, t_stop: int = 0) -> torch.Tensor:
+        """z: [S,C,H,W] fp32 start noise; labels: [S] long.  Guidance is 0.0 for samples whose label is the
+        unconditional id (reference visualization.py:424).  ``noises[t]`` overrides the RNG (tests);
+        ``t_stop>0`` stops after step t_stop (bounded timing runs) and returns the un-clamped latent."""
+        from . import kernels as K
+        model = self.model
+        model.eval()
+        S = z.shape[0]
+        T = num_time_steps or self.sched.T
+        dev = z.device
+        beta, abar = self.sched.beta_cpu, self.sched.alpha_bar_cpu
+        labels = labels.to(dev).long()
+        g = torch.full((S,), float(guidance_scale), dtype=torch.float32)
+        g[labels.cpu() == self.uncond_id] = 0.0
+        table = self.table.to(dev)
+        ctx = torch.cat([table[torch.full_like(labels, self.uncond_id)], table[labels]]).contiguous()
+        z = z.contiguous().clone()
+        zz = torch.empty((2 * S, *z.shape[1:]), dtype=torch.float32, device=dev)
+        for t in range(T - 1, -1, -1):
+            if t < t_stop:
+                return z
+            final = (t == 0)
+            coef = step_coefficients(beta, abar, t, g, eta, S, final=final).to(dev, non_blocking=True)
+            zz[:S].copy_(z)
+            zz[S:].copy_(z)
+            tt = torch.full((2 * S,), t, dtype=torch.long, device=dev)
+            v, _ = model._fwd(zz, tt, ctx)
+            noise = None
+            if (not final) and t > 1 and eta > 0.0:
+                if noises is not None and t in noises:
+                    noise = noises[t].to(dev)
+                else:
+                    noise = torch.randn(z.shape, dtype=torch.float32, device=dev, generator=generator)
+            else:
+                noise = z  # unused (coef[4] == 0)
+            z = K.cfg_ddpm_step(z, v[:S], v[S:], noise, coef)
+        return z

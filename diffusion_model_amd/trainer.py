@@ -1,0 +1,198 @@
+"""The training hot loop of the reference (main_stl10.py:449-516, main.py:159-188) on the HIP kernels.
+
+* parameters, gradients, Adam moments and the EMA copy each live in ONE flat fp32 buffer
+  (``FlatParams``); module parameters are views, so ``state_dict()`` / checkpoints are unchanged;
+* a micro-step is: fused q-sample + target -> hand-scheduled UNet forward -> fused weighted-MSE
+  loss + dL/dout -> hand-scheduled backward accumulating straight into the flat gradient;
+* an optimizer step is 3 launches: squared-norm partials, norm + clip coefficient, fused
+  clip-scale + AdamW + EMA (the 1/world_size gradient average rides in the same multiply);
+* data parallel: one process per GPU, the flat gradient is all-reduced (RCCL) in a few large
+  contiguous buckets, each enqueued the moment its layers' backward has been launched, so the
+  collective overlaps the rest of the backward; only on accumulation boundaries.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .unet import Grads, invalidate_packed_weights
+
+
+def lr_lambda(step: int, total_steps: int) -> float:
+    """Reference main_stl10.py:405-412: 5 % linear warm-up, then cosine."""
+    warm = max(1, int(0.05 * total_steps))
+    if step < warm:
+        return float(step + 1) / float(max(1, warm))
+    prog = (step - warm) / float(max(1, total_steps - warm))
+    return 0.5 * (1.0 + math.cos(math.pi * prog))
+
+
+class FlatParams:
+    """Re-homes a module's parameters into one flat fp32 buffer (16-byte aligned slices)."""
+
+    def __init__(self, model: nn.Module):
+        self.model = model
+        self.params = list(model.parameters())
+        dev = self.params[0].device
+        self.offsets: List[Tuple[int, int]] = []
+        off = 0
+        for p in self.params:
+            self.offsets.append((off, p.numel()))
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_views: Dict[int, torch.Tensor] = {}
+        with torch.no_grad():
+            for p, (o, n) in zip(self.params, self.offsets):
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                self.grad_views[id(p)] = self.grad[o:o + n].view(p.shape)
+        invalidate_packed_weights()
+
+    def view_like(self, flat: torch.Tensor, module: nn.Module) -> None:
+        """Point ``module``'s parameters (same structure as the model) at slices of ``flat``."""
+        for p, (o, n) in zip(module.parameters(), self.offsets):
+            p.data = flat[o:o + n].view(p.shape)
+
+    def ranges_for(self, names: Sequence[str]) -> List[Tuple[int, int]]:
+        """Merged [start, end) ranges of the parameters whose name starts with one of ``names``."""
+        out: List[List[int]] = []
+        for (n, _), (o, cnt) in zip(self.model.named_parameters(), self.offsets):
+            if any(n.startswith(pref) for pref in names):
+                end = o + (cnt + 3) // 4 * 4
+                if out and out[-1][1] == o:
+                    out[-1][1] = end
+                else:
+                    out.append([o, end])
+        return [(a, b) for a, b in out]
+
+
+class GradBuckets:
+    """Data-parallel gradient exchange over the flat gradient buffer: a handful of large contiguous
+    buckets in reverse execution order (head, Layer4, ..., Layer1, tail), each all-reduced (SUM)
+    asynchronously as soon as the backward of its layers has been enqueued."""
+
+    def __init__(self, fp: FlatParams, stage_names: Sequence[str], process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.fp = fp
+        self.stage_ranges: Dict[str, List[Tuple[int, int]]] = {}
+        covered = 0
+        for st, prefixes in stage_names:
+            r = fp.ranges_for(prefixes)
+            self.stage_ranges[st] = r
+            covered += sum(b - a for a, b in r)
+        assert covered == fp.total, "every parameter must belong to exactly one bucket"
+        self.pending = []
+
+    def launch(self, stage: str) -> None:
+        if self.world == 1:
+            return
+        for a, b in self.stage_ranges[stage]:
+            self.pending.append(self.dist.all_reduce(self.fp.grad[a:b], op=self.dist.ReduceOp.SUM,
+                                                     group=self.pg, async_op=True))
+
+    def wait(self) -> None:
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+def unet_stage_names(model) -> List[Tuple[str, List[str]]]:
+    L = model.num_layers
+    stages = [("head", ["late_conv1", "late_conv2", "output_conv"])]
+    stages += [(f"Layer{i + 1}", [f"Layer{i + 1}."]) for i in range(L - 1, -1, -1)]
+    stages += [("tail", ["input_conv", "time_mlp"])]
+    return stages
+
+
+class Trainer:
+    """One object per process (= per GPU)."""
+
+    def __init__(self, model, scheduler, *, lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99), eps=1e-8,
+                 clip=1.0, ema_decay=0.995, accum=2, total_steps=100000, start_step=0,
+                 low_t_weight: Optional[float] = 0.01, target="v", adamw=True, ema=None,
+                 distributed=False, process_group=None):
+        self.model, self.scheduler = model, scheduler
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.clip, self.ema_decay, self.accum = clip, ema_decay, max(1, accum)
+        self.total_steps, self.low_t_weight, self.target, self.adamw = total_steps, low_t_weight, target, adamw
+        self.fp = FlatParams(model)
+        dev = self.fp.flat.device
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.ema = ema
+        self.ema_flat = None
+        if ema is not None:
+            self.ema_flat = torch.zeros_like(self.fp.flat)
+            with torch.no_grad():
+                for p, (o, n) in zip(ema.module.parameters(), self.fp.offsets):
+                    self.ema_flat[o:o + n].copy_(p.detach().reshape(-1))
+            self.fp.view_like(self.ema_flat, ema.module)
+        self.grads = Grads(self.fp.grad_views)
+        self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.opt_step = 0          # optimizer steps taken
+        self.sched_step = start_step
+        self.micro = 0
+        self.defer_optimizer = False   # tests: inspect the accumulated gradient before stepping
+        self.world = 1
+        self.buckets = None
+        if distributed:
+            self.buckets = GradBuckets(self.fp, unet_stage_names(model), process_group)
+            self.world = self.buckets.world
+        model._bwd_hook = None
+
+    # ------------------------------------------------------------------ one micro-batch
+    def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+        """x,e: [B,C,H,W] fp32 on the device; t: [B] long (device); context: [B,D] fp32 or None.
+        Returns the (un-synchronised) loss tensor [1]."""
+        B = x.shape[0]
+        chw = x.numel() // B
+        abar = self.scheduler.alpha_t[t].contiguous()
+        xt, v = K.qsample_vtarget(x, e, abar)
+        tgt = v if self.target == "v" else e
+        last = (self.micro + 1) % self.accum == 0
+        y, saved = self.model._fwd(xt, t, context)
+        if self.low_t_weight is None:
+            w = torch.full((B,), 1.0 / (B * chw), dtype=torch.float32, device=x.device)
+        else:
+            w = torch.exp(-self.low_t_weight * t.float()) / (B * chw)
+        loss, dout = K.mse_loss_fwd_bwd(y, tgt, w.contiguous(), grad_scale=1.0 / self.accum)
+        if self.buckets is not None and last:
+            self.model._bwd_hook = self.buckets.launch
+        self.model._bwd(dout, saved, self.grads)
+        self.model._bwd_hook = None
+        self.micro += 1
+        if last and not self.defer_optimizer:
+            self.optimizer_step()
+        return loss
+
+    # ------------------------------------------------------------------ clip + AdamW + EMA
+    def current_lr(self) -> float:
+        return self.lr * lr_lambda(self.sched_step, self.total_steps)
+
+    def optimizer_step(self) -> None:
+        if self.buckets is not None:
+            self.buckets.wait()
+        pre = 1.0 / self.world
+        clipbuf = None
+        if self.clip and self.clip > 0:
+            K.grad_norm_clipcoef(self.fp.grad, self.clip, pre_scale=pre, out=self.norm)
+            clipbuf = self.norm
+        self.opt_step += 1
+        K.adamw_ema_step(self.fp.flat, self.fp.grad, self.m, self.v, self.ema_flat, clipbuf, lr=self.current_lr(),
+                         beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self.opt_step,
+                         ema_decay=self.ema_decay, pre_scale=pre, adamw=self.adamw)
+        self.sched_step += 1
+        self.fp.grad.zero_()
+        invalidate_packed_weights()
+
+    def grad_norm(self) -> float:
+        return float(self.norm[0].item())

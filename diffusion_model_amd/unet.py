@@ -596,6 +596,8 @@ class UNET(HipModule):
         d_a1 = K.silu_bwd(d_s1, a1)
         K.wgrad(cat, d_a1, g.of(self.late_conv1.weight), g.of(self.late_conv1.bias))
         d_cat = K.conv3x3(d_a1, PW.of(self.late_conv1).bwd, Cc)
+        hook = self.__dict__.get("_bwd_hook") or (lambda stage: None)
+        hook("head")
         dts = None
         d_skips: List[Optional[torch.Tensor]] = [None] * L
         da = None
@@ -603,10 +605,11 @@ class UNET(HipModule):
             c_dec = self.Channels[i + 1] // 2
             d_skips[L - 1 - i] = d_cat[..., c_dec:]
             da, dts = self.layers()[i]._bwd(d_cat[..., :c_dec], None, saved_layers[i], g, dts)
+            hook(f"Layer{i + 1}")
             d_cat = da  # gradient wrt this decoder layer's input = previous concat buffer (or encoder output)
         for i in range(half - 1, -1, -1):
-            last = (i == 0)
             da, dts = self.layers()[i]._bwd(da, d_skips[i], saved_layers[i], g, dts, need_dx=True)
+            hook(f"Layer{i + 1}")
         # input conv
         ic = self.input_conv
         K.wgrad(x0, da, g.of(ic.weight), g.of(ic.bias), k_valid=self.cin)
@@ -625,6 +628,7 @@ class UNET(HipModule):
         dsh1 = K.gemm(dtemb, PW.of(l2).bwd, self.temb_dim)
         dh1 = K.silu_bwd(dsh1, h1)
         K.wgrad(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
+        hook("tail")
         return dx
 
     # ------------------------------------------------------------------ public API

@@ -33,6 +33,9 @@ typedef void* dm_stream_t;
 /* ABI version / arch string ("gfx950"). */
 int dm_abi_version(void);
 const char* dm_target_arch(void);
+/* Text of the HIP error behind the calling thread's last DM_ERR_LAUNCH ("" if none). */
+const char* dm_last_hip_error(void);
+void dm_note_hip_error(int code);
 
 /* ------------------------------------------------------------------ weights */
 /* Bytes of the packed bf16 shadow of an [N][K][taps] weight (N padded to 16, K to 64). */
