@@ -30,7 +30,7 @@ struct AttnParams {
   float* delta;
   int B, H, Nq, Nk, hd;
   float scale;
-  uint64_t seed; uint32_t thresh; float inv_keep;
+  uint32_t seed; uint32_t thresh; float inv_keep;  // dm_common.h dropout convention
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
@@ -126,19 +126,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       const float alpha = exp2f(m[qt] - mn);
       m[qt] = mn;
       float ps = 0.f;
+      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) : 0u;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        uint32_t db0 = 0u, db1 = 0u;
+        if (p.thresh) {
+          const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
+          db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pv = exp2f(st[kt][qt][r] - mn);
           ps += pv;
-          if (p.thresh) {
-            const int key = kb * 64 + kt * 16 + 4 * g + r;
-            const uint64_t idx = ((uint64_t)bh * p.Nq + qi[qt]) * p.Nk + key;
-            pv = dm_keep(p.seed, idx, p.thresh) ? pv * p.inv_keep : 0.f;
-          }
+          if (p.thresh) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv * p.inv_keep : 0.f;
           st[kt][qt][r] = pv;
         }
+      }
       l[qt] = l[qt] * alpha + ps;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc[dt][qt] *= alpha;
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
         float pv = (key_ok && q < p.Nq) ? exp2f(s[r] * c - sL[ql]) : 0.f;
         float pd = pv, dpv = dp[r];
         if (p.thresh) {
-          const uint64_t idx = ((uint64_t)bh * p.Nq + q) * p.Nk + key;
-          const bool keep = dm_keep(p.seed, idx, p.thresh);
+          const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+          const bool keep = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh);
           pd = keep ? pv * p.inv_keep : 0.f;
           dpv = keep ? dpv * p.inv_keep : 0.f;
         }
@@ -324,15 +327,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
       for (int qt = 0; qt < 2; ++qt) {
         const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        uint32_t db0 = 0u, db1 = 0u;
+        if (p.thresh) {
+          const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
+          const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
+          db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 64 + kt * 16 + 4 * g + r;
           const float pv = (key < p.Nk && qi[qt] < p.Nq) ? exp2f(s[r] * c - Lq[qt]) : 0.f;
           float dpv = dp[r];
-          if (p.thresh) {
-            const uint64_t idx = ((uint64_t)bh * p.Nq + qi[qt]) * p.Nk + key;
-            dpv = dm_keep(p.seed, idx, p.thresh) ? dpv * p.inv_keep : 0.f;
-          }
+          if (p.thresh) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv * p.inv_keep : 0.f;
           ds[kt][qt][r] = pv * (dpv - Dq[qt]);
         }
       }
@@ -367,6 +373,191 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------- few-token cross-attention
+// Nk <= 16 context tokens (the CLIP table gives exactly ONE): a 64-key flash tile would be >= 75 %
+// masked, so these kernels drop MFMA altogether.  HBM-bound: q / dO are read, o / dq written, once.
+//   phase 1, thread = (query, head): scores against the Nk keys (K, V of the sample live in LDS as
+//            fp32), softmax, dropout mask -> per-(query, head, key) scalars in LDS;
+//   phase 2, thread = channel (coalesced rows): o = sum_k p_k V_k  (fwd) /
+//            dq = sum_k ds_k K_k, and dK_k, dV_k accumulated in registers over the block's queries,
+//            then ONE fp32 atomic per (key, channel) per block into a [B,Nk,C] scratch.
+constexpr int SMALL_NK = 16;
+constexpr int SMALL_CHUNKS = 8;  // query chunks (of 256/H queries) per block
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int H = p.H, C = H * HD, Nk = p.Nk, QB = 256 / H;
+  float* sK = sm; float* sV = sK + Nk * C; float* sP = sV + Nk * C;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < Nk * C; i += 256) {
+    const int k = i / C, c = i % C;
+    sK[i] = (float)p.k[((long)b * Nk + k) * p.ldk + c];
+    sV[i] = (float)p.v[((long)b * Nk + k) * p.ldv + c];
+  }
+  __syncthreads();
+  const int ql = tid / H, h = tid % H;
+  for (int ch = 0; ch < SMALL_CHUNKS; ++ch) {
+    const int q0 = (blockIdx.x * SMALL_CHUNKS + ch) * QB;
+    if (q0 >= p.Nq) break;
+    const int q = q0 + ql;
+    if (q < p.Nq && ql < QB) {
+      float qv[HD];
+      const bf16* qp = p.q + ((long)b * p.Nq + q) * p.ldq + h * HD;
+#pragma unroll
+      for (int j = 0; j < HD; j += 8) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[j + e] = (float)t[e];
+      }
+      float s[SMALL_NK];
+      float m = NEG;
+#pragma unroll
+      for (int k = 0; k < SMALL_NK; ++k) {
+        s[k] = NEG;
+        if (k < Nk) {
+          float a = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) a += qv[d] * sK[k * C + h * HD + d];
+          s[k] = a * p.scale;
+          m = fmaxf(m, s[k]);
+        }
+      }
+      float l = 0.f;
+#pragma unroll
+      for (int k = 0; k < SMALL_NK; ++k)
+        if (k < Nk) { s[k] = __expf(s[k] - m); l += s[k]; }
+      const float inv = 1.f / l;
+      const int bh = b * H + h;
+      if (p.lse) p.lse[(long)bh * p.Nq + q] = m + __logf(l);
+      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) : 0u;
+#pragma unroll
+      for (int k = 0; k < SMALL_NK; ++k)
+        if (k < Nk) {
+          float pv = s[k] * inv;
+          if (p.thresh) pv = dm_keep16(dm_drop_bits(rs, (uint32_t)k >> 1), (uint32_t)k, p.thresh) ? pv * p.inv_keep : 0.f;
+          sP[(ql * H + h) * Nk + k] = pv;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QB * C; i += 256) {
+      const int qq = i / C, c = i % C, hh = c / HD;
+      if (q0 + qq < p.Nq) {
+        float o = 0.f;
+        for (int k = 0; k < Nk; ++k) o += sP[(qq * H + hh) * Nk + k] * sV[k * C + c];
+        p.o[((long)b * p.Nq + q0 + qq) * p.ldo + c] = (bf16)o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const AttnParams p, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int H = p.H, C = H * HD, Nk = p.Nk, QB = 256 / H;
+  float* sK = sm; float* sV = sK + Nk * C; float* sDS = sV + Nk * C; float* sPD = sDS + QB * H * Nk;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < Nk * C; i += 256) {
+    const int k = i / C, c = i % C;
+    sK[i] = (float)p.k[((long)b * Nk + k) * p.ldk + c];
+    sV[i] = (float)p.v[((long)b * Nk + k) * p.ldv + c];
+  }
+  __syncthreads();
+  const int ql = tid / H, h = tid % H;
+  const int P = 256 / C;                 // phase-2 thread groups (C <= 256)
+  const int c2 = tid % C, part = tid / C, h2 = c2 / HD;
+  float accK[SMALL_NK], accV[SMALL_NK];
+#pragma unroll
+  for (int k = 0; k < SMALL_NK; ++k) { accK[k] = 0.f; accV[k] = 0.f; }
+  for (int ch = 0; ch < SMALL_CHUNKS; ++ch) {
+    const int q0 = (blockIdx.x * SMALL_CHUNKS + ch) * QB;
+    if (q0 >= p.Nq) break;
+    const int q = q0 + ql;
+    if (q < p.Nq && ql < QB) {
+      float qv[HD], dv_[HD];
+      const bf16* qp = p.q + ((long)b * p.Nq + q) * p.ldq + h * HD;
+      const bf16* dp = p.d_o + ((long)b * p.Nq + q) * p.lddo + h * HD;
+#pragma unroll
+      for (int j = 0; j < HD; j += 8) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(qp + j);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(dp + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qv[j + e] = (float)t[e]; dv_[j + e] = (float)u[e]; }
+      }
+      const int bh = b * H + h;
+      const float L = p.lse[(long)bh * p.Nq + q];
+      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) : 0u;
+      float pk[SMALL_NK], dP[SMALL_NK];
+      float delta = 0.f;
+#pragma unroll
+      for (int k = 0; k < SMALL_NK; ++k) {
+        pk[k] = 0.f; dP[k] = 0.f;
+        if (k < Nk) {
+          float a = 0.f, d2 = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) {
+            a += qv[d] * sK[k * C + h * HD + d];
+            d2 += dv_[d] * sV[k * C + h * HD + d];
+          }
+          pk[k] = __expf(a * p.scale - L);
+          float keepf = 1.f;
+          if (p.thresh) keepf = dm_keep16(dm_drop_bits(rs, (uint32_t)k >> 1), (uint32_t)k, p.thresh) ? p.inv_keep : 0.f;
+          dP[k] = d2 * keepf;
+          delta += pk[k] * dP[k];
+          sPD[(ql * H + h) * Nk + k] = pk[k] * keepf;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SMALL_NK; ++k)
+        if (k < Nk) sDS[(ql * H + h) * Nk + k] = pk[k] * (dP[k] - delta) * p.scale;
+    }
+    __syncthreads();
+    if (part < P) {
+      for (int qq = part; qq < QB; qq += P) {
+        const int q2 = q0 + qq;
+        if (q2 >= p.Nq) break;
+        const float qc = (float)p.q[((long)b * p.Nq + q2) * p.ldq + c2];
+        const float dc = (float)p.d_o[((long)b * p.Nq + q2) * p.lddo + c2];
+        float dq = 0.f;
+#pragma unroll
+        for (int k = 0; k < SMALL_NK; ++k)
+          if (k < Nk) {
+            const float ds = sDS[(qq * H + h2) * Nk + k];
+            dq += ds * sK[k * C + c2];
+            accK[k] += ds * qc;
+            accV[k] += sPD[(qq * H + h2) * Nk + k] * dc;
+          }
+        p.dq[((long)b * p.Nq + q2) * p.lddq + c2] = (bf16)dq;
+      }
+    }
+    __syncthreads();
+  }
+  if (part < P) {
+#pragma unroll
+    for (int k = 0; k < SMALL_NK; ++k)
+      if (k < Nk) {
+        atomicAdd(ws + ((long)b * Nk + k) * C + c2, accK[k]);
+        atomicAdd(ws + (long)p.B * Nk * C + ((long)b * Nk + k) * C + c2, accV[k]);
+      }
+  }
+}
+
+__global__ void attn_small_finish_kernel(const AttnParams p, const float* __restrict__ ws, int C) {
+  const long n = (long)p.B * p.Nk * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bk = i / C;
+    p.dk[bk * p.lddk + c] = (bf16)ws[i];
+    p.dv[bk * p.lddv + c] = (bf16)ws[n + i];
+  }
+}
+
+bool small_ok(const AttnParams& p) {
+  const int C = p.H * p.hd;
+  return p.Nk <= SMALL_NK && C <= 256 && 256 % p.H == 0 && 256 % C == 0;
+}
+
 int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   DM_REQUIRE(a && a->q && a->k && a->v && a->o && a->lse);
   DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32);
@@ -382,9 +573,9 @@ int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   p.d_o = (const bf16*)a->d_o; p.lddo = a->lddo; p.dq = (bf16*)a->dq; p.lddq = a->lddq;
   p.dk = (bf16*)a->dk; p.lddk = a->lddk; p.dv = (bf16*)a->dv; p.lddv = a->lddv; p.delta = a->delta;
   p.B = a->B; p.H = a->heads; p.Nq = a->Nq; p.Nk = a->Nk; p.hd = a->hd; p.scale = a->scale;
-  p.seed = a->drop_seed;
-  p.thresh = a->drop_p > 0.f ? (uint32_t)((double)a->drop_p * 4294967296.0) : 0u;
-  p.inv_keep = a->drop_p > 0.f ? 1.f / (1.f - a->drop_p) : 1.f;
+  p.seed = dm_seed32(a->drop_seed);
+  p.thresh = dm_thresh16(a->drop_p);
+  p.inv_keep = dm_inv_keep(a->drop_p);
   return DM_OK;
 }
 
@@ -394,6 +585,16 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   AttnParams p{};
   const int rc = fill(p, a, false);
   if (rc != DM_OK) return rc;
+  if (small_ok(p)) {
+    const int C = p.H * p.hd, QB = 256 / p.H;
+    const dim3 g((p.Nq + QB * SMALL_CHUNKS - 1) / (QB * SMALL_CHUNKS), p.B);
+    const size_t lds = (size_t)(2 * p.Nk * C + QB * p.H * p.Nk) * sizeof(float);
+    if (p.hd == 8) hipLaunchKernelGGL(attn_small_fwd_kernel<8>, g, dim3(256), lds, (hipStream_t)stream, p);
+    else if (p.hd == 16) hipLaunchKernelGGL(attn_small_fwd_kernel<16>, g, dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_small_fwd_kernel<32>, g, dim3(256), lds, (hipStream_t)stream, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   const dim3 grid((p.Nq + 127) / 128, p.B * p.H);
   if (p.hd > 16) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -406,6 +607,21 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   const int rc = fill(p, a, true);
   if (rc != DM_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (small_ok(p)) {
+    // p.delta doubles as the fp32 [2][B,Nk,C] reduction scratch (the caller sizes it: dm_hip.h)
+    const int C = p.H * p.hd, QB = 256 / p.H;
+    float* ws = p.delta;
+    if (hipMemsetAsync(ws, 0, (size_t)2 * p.B * p.Nk * C * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+    const dim3 g((p.Nq + QB * SMALL_CHUNKS - 1) / (QB * SMALL_CHUNKS), p.B);
+    const size_t lds = (size_t)(2 * p.Nk * C + 2 * QB * p.H * p.Nk) * sizeof(float);
+    if (p.hd == 8) hipLaunchKernelGGL(attn_small_bwd_kernel<8>, g, dim3(256), lds, st, p, ws);
+    else if (p.hd == 16) hipLaunchKernelGGL(attn_small_bwd_kernel<16>, g, dim3(256), lds, st, p, ws);
+    else hipLaunchKernelGGL(attn_small_bwd_kernel<32>, g, dim3(256), lds, st, p, ws);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_small_finish_kernel, dim3(64), dim3(256), 0, st, p, (const float*)ws, C);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   const long total = (long)p.B * p.H * p.Nq;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -49,14 +49,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Counter-based RNG (splitmix64 finaliser over (seed, index)); returns 32 uniform bits.
 // Used for dropout masks so the backward can regenerate the forward's mask from (seed, index)
 // without storing it.  (torch's Philox stream cannot be matched bit-for-bit)
-__device__ __forceinline__ uint32_t dm_rng32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+// The mask of element (row, col) is a pure function of (seed, row, col): two 32-bit
+// multiply-xorshift stages; one 32-bit draw serves the column PAIR (col>>1) with 16 bits each, so a
+// lane that owns consecutive columns pays ~4 VALU ops per element (the 64-bit splitmix used first
+// cost ~30 and dominated the attention kernels).  keep iff bits16 >= thresh16 = round(p * 65536).
+__device__ __forceinline__ uint32_t dm_drop_row(uint32_t seed, uint32_t row) {
+  uint32_t x = row * 0x9E3779B1u + seed;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  return x;
 }
-// keep-probability threshold: keep iff rng32 >= p * 2^32
-__device__ __forceinline__ bool dm_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return dm_rng32(seed, idx) >= thresh;
+__device__ __forceinline__ uint32_t dm_drop_bits(uint32_t rowstate, uint32_t pair) {
+  uint32_t x = rowstate + pair * 0x846CA68Bu;
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  x *= 0x297A2D39u;
+  x ^= x >> 15;
+  return x;
 }
+__device__ __forceinline__ bool dm_keep16(uint32_t bits32, uint32_t col, uint32_t thresh16) {
+  return ((col & 1u) ? (bits32 >> 16) : (bits32 & 0xFFFFu)) >= thresh16;
+}
+// host side of the same convention
+static inline uint32_t dm_thresh16(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
+static inline float dm_inv_keep(float p) { return p > 0.f ? 65536.0f / (65536.0f - (float)dm_thresh16(p)) : 1.f; }
+static inline uint32_t dm_seed32(unsigned long long s) { return (uint32_t)(s ^ (s >> 32)) * 0x9E3779B1u + 0x7F4A7C15u; }

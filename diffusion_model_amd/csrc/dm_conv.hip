@@ -43,7 +43,7 @@ struct ConvParams {
   int pool2;                     // sum 2x2 output pixels (dgrad of nearest-x2)
   int act_silu_in;               // apply SiLU to the input while staging
   // dropout on the output (after bias/chan_add, before res): keep iff rng>=thresh, scale
-  uint64_t drop_seed; uint32_t drop_thresh; float drop_scale;
+  uint32_t drop_seed; uint32_t drop_thresh; float drop_scale;  // dm_common.h dropout convention
 };
 
 template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
@@ -249,9 +249,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       f32x4 v = acc[mt][nt] + bias4;
       if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
       if (p.drop_thresh) {
+        const uint32_t rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
+        const uint32_t b0 = dm_drop_bits(rs, (uint32_t)co >> 1), b1 = dm_drop_bits(rs, ((uint32_t)co >> 1) + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          v[j] = dm_keep(p.drop_seed, (uint64_t)pix * p.Cout + co + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+          v[j] = dm_keep16(j < 2 ? b0 : b1, (uint32_t)j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
       }
       if (p.res) {
         const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
@@ -364,12 +366,12 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
   p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
   p.pool2 = a->pool2; p.act_silu_in = a->act_silu_in;
-  p.drop_seed = a->drop_seed; p.drop_scale = 1.0f;
+  p.drop_seed = dm_seed32(a->drop_seed); p.drop_scale = 1.0f;
   p.drop_thresh = 0;
   if (a->drop_p > 0.f) {
     DM_REQUIRE(a->drop_p < 1.f);
-    p.drop_thresh = (uint32_t)((double)a->drop_p * 4294967296.0);
-    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_thresh = dm_thresh16(a->drop_p);
+    p.drop_scale = dm_inv_keep(a->drop_p);
   }
   hipStream_t st = (hipStream_t)stream;
   const int mode = a->mode;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const bf16* __restrict__ x, long ldx, const float* __restrict__ chan_add, const bf16* __restrict__ dy,
     long lddy, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
     const float* __restrict__ ws, int nsplit, float* __restrict__ sums, const bf16* __restrict__ add_in, long ldadd,
-    bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint64_t drop_seed,
+    bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
     uint32_t drop_thresh, float drop_scale) {
   __shared__ float s_s1[256], s_s2[256], s_m1[64], s_m2[64];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     bf16x8 a8;
     if (add_in) a8 = *reinterpret_cast<const bf16x8*>(add_in + gp * ldadd + c0);
     bf16x8 o;
+    uint32_t db[4] = {0u, 0u, 0u, 0u};
+    if (drop_thresh) {
+      const uint32_t rs = dm_drop_row(drop_seed, (uint32_t)gp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) db[j] = dm_drop_bits(rs, ((uint32_t)c0 >> 1) + j);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = ((float)v[j] + add[j] - mean) * rstd;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
         dz *= sg * (1.f + z * (1.f - sg));
       }
       float r = rstd * (dz * ga[j] - m1 - xh * m2);
-      if (drop_thresh) r = dm_keep(drop_seed, (uint64_t)gp * C + c0 + j, drop_thresh) ? r * drop_scale : 0.f;
+      if (drop_thresh) r = dm_keep16(db[j >> 1], (uint32_t)j, drop_thresh) ? r * drop_scale : 0.f;
       if (add_in) r += (float)a8[j];
       o[j] = (bf16)r;
     }
@@ -304,11 +310,11 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, ws, HW, C, G, ns, act_silu);
   DM_LAUNCH_CHECK();
-  const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-  const float scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh = dm_thresh16(drop_p);
+  const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, ws, ns, sums, (const bf16*)add_in, ldadd, (bf16*)dx,
-                     lddx, HW, C, G, ns, act_silu, (uint64_t)drop_seed, thresh, scale);
+                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale);
   DM_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dgamma, dbeta, B, C);
   DM_LAUNCH_CHECK();

@@ -213,7 +213,8 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     dq = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if dq is None else dq
     dk = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dk is None else dk
     dv = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dv is None else dv
-    delta = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
+    # scratch: rowsum(dO*O) [B,heads,Nq]; the few-token path reuses it as the [2,B,Nk,C] fp32 dK/dV reduction
+    delta = torch.empty(max(B * heads * Nq, 2 * B * Nk * Cc), dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
     a.d_o, a.lddo = _p(d_o), _act(d_o, "d_o")
     a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
