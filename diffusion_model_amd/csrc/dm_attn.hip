@@ -108,22 +108,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       for (int qt = 0; qt < 2; ++qt)
         st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
+    // Per-element VALU budget (the bound of these small-head kernels): max, fma, v_exp, add, half a
+    // cvt_pk.  The key-range mask is applied only in the last, partial key block; the softmax scale
+    // rides in the fma; v_exp_f32 is issued raw (no denormal range fix-up: p < 2^-126 is 0 anyway).
+    const bool edge = kb * 64 + 64 > p.Nk;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float bm = NEG;
+      if (edge) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kb * 64 + kt * 16 + 4 * g + r >= p.Nk) st[kt][qt][r] = NEG;
+      }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kb * 64 + kt * 16 + 4 * g + r;
-          const float s = (key < p.Nk) ? st[kt][qt][r] * c : NEG;
-          st[kt][qt][r] = s;
-          bm = fmaxf(bm, s);
-        }
+        for (int r = 0; r < 4; ++r) bm = fmaxf(bm, st[kt][qt][r]);
       bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
       bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m[qt], bm);
-      const float alpha = exp2f(m[qt] - mn);
+      const float mn = fmaxf(m[qt], bm * c);
+      const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
       m[qt] = mn;
       float ps = 0.f;
       const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) : 0u;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = exp2f(st[kt][qt][r] - mn);
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][qt][r], c, -mn));
           ps += pv;
           if (p.thresh) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv * p.inv_keep : 0.f;
           st[kt][qt][r] = pv;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
     stage_block(sO, p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
     if (tid < 64) {
       const int q = qb * 64 + tid;
-      sL[tid] = (q < p.Nq) ? p.lse[(long)bh * p.Nq + q] * LOG2E : 0.f;
+      sL[tid] = (q < p.Nq) ? p.lse[(long)bh * p.Nq + q] * LOG2E : 1e30f;  // out-of-range query: p = exp2(-huge) = 0
       sD[tid] = (q < p.Nq) ? p.delta[(long)bh * p.Nq + q] : 0.f;
     }
     __syncthreads();
@@ -243,7 +249,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
       for (int r = 0; r < 4; ++r) {
         const int ql = qt * 16 + 4 * g + r;
         const int q = qb * 64 + ql;
-        float pv = (key_ok && q < p.Nq) ? exp2f(s[r] * c - sL[ql]) : 0.f;
+        // no per-element masks: invalid queries carry L = +1e30 (p = 0); invalid keys only pollute their
+        // own (never stored) dK/dV columns
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -sL[ql]));
         float pd = pv, dpv = dp[r];
         if (p.thresh) {
           const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
     const bool ok = qi[qt] < p.Nq;
     qf[qt] = load_row_frag(p.q, p.ldq, qbase + qi[qt], ok, hoff, p.hd, g);
     dof[qt] = load_row_frag(p.d_o, p.lddo, qbase + qi[qt], ok, hoff, p.hd, g);
-    Lq[qt] = ok ? p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : 0.f;
+    Lq[qt] = ok ? p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : 1e30f;  // out-of-range query: p = 0
     Dq[qt] = ok ? p.delta[(long)bh * p.Nq + qi[qt]] : 0.f;
   }
   f32x4 dqT[DT][2];
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
     stage_block(sV, p.v, p.ldv, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
     __syncthreads();
     f32x4 ds[4][2];
+    const bool edge = kb * 64 + 64 > p.Nk;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
@@ -336,7 +345,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 64 + kt * 16 + 4 * g + r;
-          const float pv = (key < p.Nk && qi[qt] < p.Nq) ? exp2f(s[r] * c - Lq[qt]) : 0.f;
+          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lq[qt]));
+          if (edge && key >= p.Nk) pv = 0.f;  // key-range mask only in the last, partial key block
           float dpv = dp[r];
           if (p.thresh) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv * p.inv_keep : 0.f;
           ds[kt][qt][r] = pv * (dpv - Dq[qt]);

@@ -204,9 +204,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                     float* __restrict__ dbias, int nsplit, int ncot, int ncit, int taps, int Kreal,
                                     int Nreal) {
+  // grid.x walks the accumulator elements, grid.y cuts the split-K range into groups so that
+  // enough independent loads are in flight to stream the slabs at HBM rate; each group folds
+  // its partial into dw with one hardware fp32 atomic per element.
   const long slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
   const long per_tile = (long)taps * 4 * 4 * 256;
   const long total = (long)ncot * ncit * per_tile;
+  const int per_group = (nsplit + gridDim.y - 1) / gridDim.y;
+  const int sp0 = blockIdx.y * per_group;
+  const int sp1 = min(nsplit, sp0 + per_group);
+  const long sp_stride = (long)ncot * ncit * slab_floats;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long tile = i / per_tile;
     const int e = (int)(i % per_tile);
@@ -215,9 +222,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int co = cot * 64 + t * 16 + (lane >> 4) * 4 + reg;
     const int ci = cit * 64 + wave * 16 + (lane & 15);
     if (co >= Nreal || ci >= Kreal) continue;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slab[(((long)sp * ncot + cot) * ncit + cit) * slab_floats + e];
-    dw[((long)co * Kreal + ci) * taps + tap] += s;
+    const float* src = slab + ((long)cot * ncit + cit) * slab_floats + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = sp0;
+    for (; sp + 4 <= sp1; sp += 4) {
+      s0 += src[(long)sp * sp_stride];
+      s1 += src[(long)(sp + 1) * sp_stride];
+      s2 += src[(long)(sp + 2) * sp_stride];
+      s3 += src[(long)(sp + 3) * sp_stride];
+    }
+    for (; sp < sp1; ++sp) s0 += src[(long)sp * sp_stride];
+    float* dst = dw + ((long)co * Kreal + ci) * taps + tap;
+    const float s = (s0 + s1) + (s2 + s3);
+    if (gridDim.y == 1) *dst += s; else unsafeAtomicAdd(dst, s);
   }
   if (dbias) {
     const long totalb = (long)ncot * 64;
@@ -227,10 +244,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
       if (co >= Nreal) continue;
       const int t = cl >> 4, q = (cl & 15) >> 2, reg = cl & 3;
       const int e = (t * 64 + q * 16) * 4 + reg;  // lane = q*16 (column 0)
-      float s = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp)
-        s += slab[(((long)sp * ncot + cot) * ncit + 0) * slab_floats + per_tile + e];
-      dbias[co] += s;
+      const float* src = slab + ((long)cot * ncit) * slab_floats + per_tile + e;
+      float s0 = 0.f, s1 = 0.f;
+      int sp = sp0;
+      for (; sp + 2 <= sp1; sp += 2) {
+        s0 += src[(long)sp * sp_stride];
+        s1 += src[(long)(sp + 1) * sp_stride];
+      }
+      if (sp < sp1) s0 += src[(long)sp * sp_stride];
+      if (gridDim.y == 1) dbias[co] += s0 + s1; else unsafeAtomicAdd(dbias + co, s0 + s1);
     }
   }
 }
@@ -323,7 +345,10 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   const long total = (long)pl.ncot * pl.ncit * a->taps * 4096;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
+  int groups = pl.nsplit / 8;  // every group still sums >= 8 slabs in registers
+  if (groups < 1) groups = 1;
+  if (groups > 32) groups = 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
                      pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
   DM_LAUNCH_CHECK();
   return DM_OK;
