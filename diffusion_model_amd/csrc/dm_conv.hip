@@ -98,110 +98,142 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   const int vh0 = (MODE == MODE_S2) ? 2 * h0 - 1 : h0 - 1;
   const int vw0 = (MODE == MODE_S2) ? 2 * w0 - 1 : w0 - 1;
 
-  for (int cc = 0; cc < ncc; ++cc) {
-    __syncthreads();
-    // ---- stage the input patch for this channel chunk
-    for (int idx = tid; idx < PH * PW * 8; idx += 256) {
+  // ---- software pipeline over the flat stage index g = cc * NS + s.  Weight stages are linear in g
+  // (packed k-step order), so their prefetch runs two stages ahead straight through channel-chunk
+  // boundaries: stage j travels global -> br[j & 1] (issued at step j-2) -> LDS buffer j & 1 (written
+  // at the end of step j-1) -> MFMA at step j.  The halo patch of the next chunk is fetched with all
+  // its loads in flight at once, then written after the barrier that retires the current patch.
+  constexpr int A_PIECES = PH * PW * 8;
+  constexpr int NPA = (A_PIECES + 255) / 256;
+  const int G = ncc * NS;
+
+  auto load_patch = [&](int cc, u32x4(&pa)[NPA]) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int idx = tid + i * 256;
       const int piece = idx & 7;
       const int pp = idx >> 3;
       const int pr = pp / PW, pc = pp % PW;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      bool valid;
+      bool valid = idx < A_PIECES;
       long src;
       const int ch = cc * 64 + piece * 8;
       if constexpr (MODE == MODE_GEMM) {
         const long m = m0 + pp;
-        valid = (m < p.M) && (ch < p.Cin);
+        valid = valid && (m < p.M) && (ch < p.Cin);
         src = m * p.ldx + ch;
       } else {
         const int vh = vh0 + pr, vw = vw0 + pc;
         int sh = vh, sw = vw;
         if constexpr (MODE == MODE_UP) {
-          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
           sh = vh >> 1; sw = vw >> 1;
         } else if constexpr (MODE == MODE_ZI) {
-          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi) &&
+          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi) &&
                   (((vh | vw) & 1) == 0);
           sh = vh >> 1; sw = vw >> 1;
         } else {
-          valid = (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+          valid = valid && (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
         }
         src = (((long)b * p.Hi + sh) * p.Wi + sw) * p.ldx + ch;
       }
-      if (valid) {
-        v = *reinterpret_cast<const u32x4*>(p.x + src);
-        if (p.act_silu_in) {
-          bf16x8 h = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
-          v = __builtin_bit_cast(u32x4, h);
-        }
-      }
-      *reinterpret_cast<u32x4*>(sA + (pr * PITCH + pc) * STRIDE + piece * 16) = v;
+      // unconditional load (offset 0 is always readable) so that all NPA loads are in flight together
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (valid ? src : 0));
+      pa[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
     }
-    // ---- weight stages
-    auto stage_src = [&](int s, int piece) -> const char* {
-      int tap, ks, rem;
-      if constexpr (KSPS == 2) {
-        tap = s; ks = piece / (NT * 64); rem = piece % (NT * 64);
-      } else {
-        tap = s >> 1; ks = s & 1; rem = piece;
+  };
+  auto store_patch = [&](u32x4(&pa)[NPA]) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int idx = tid + i * 256;
+      const int piece = idx & 7;
+      const int pp = idx >> 3;
+      const int pr = pp / PW, pc = pp % PW;
+      u32x4 v = pa[i];
+      if (p.act_silu_in) {
+        bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
+        v = __builtin_bit_cast(u32x4, h);
       }
-      const int nt = rem >> 6, ln = rem & 63;
-      const long off = ((((long)(cc * TAPS + tap) * 2 + ks) * NTG + nb * NT + nt) * 64 + ln) * 16;
-      return p.w + off;
-    };
-    u32x4 breg[B_PER_THREAD];
+      if (A_PIECES % 256 == 0 || idx < A_PIECES)
+        *reinterpret_cast<u32x4*>(sA + (pr * PITCH + pc) * STRIDE + piece * 16) = v;
+    }
+  };
+  const char* wbase = p.w + ((long)nb * NT * 64 + 0) * 16;
+  auto load_b = [&](int g, u32x4(&br)[B_PER_THREAD]) {
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) {
       const int piece = tid + i * 256;
-      if (piece < B_PIECES) breg[i] = *reinterpret_cast<const u32x4*>(stage_src(0, piece));
+      const int ksl = piece / (NT * 64), rem = piece % (NT * 64);
+      const long off = ((long)(g * KSPS + ksl) * NTG) * 1024 + rem * 16;
+      if (B_PIECES % 256 == 0 || piece < B_PIECES) br[i] = *reinterpret_cast<const u32x4*>(wbase + off);
     }
+  };
+  auto store_b = [&](int buf, u32x4(&br)[B_PER_THREAD]) {
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) {
       const int piece = tid + i * 256;
-      if (piece < B_PIECES) *reinterpret_cast<u32x4*>(sB + piece * 16) = breg[i];
+      if (B_PIECES % 256 == 0 || piece < B_PIECES)
+        *reinterpret_cast<u32x4*>(sB + buf * B_STAGE + piece * 16) = br[i];
     }
-    __syncthreads();
+  };
 
-    for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) {
+  u32x4 br0[B_PER_THREAD], br1[B_PER_THREAD];
+  {
+    u32x4 pa[NPA];
+    load_patch(0, pa);
+    load_b(0, br0);
+    if (G > 1) load_b(1, br1);
+    store_patch(pa);
+    store_b(0, br0);
+  }
+  __syncthreads();
+
+  int s = 0, cc = 0;
+  auto step = [&](int g, u32x4(&br_free)[B_PER_THREAD], u32x4(&br_next)[B_PER_THREAD]) {
+    // br_free: register set of stage g (already in LDS) -> refill with stage g + 2
+    // br_next: holds stage g + 1 -> goes to LDS at the end of this step
+#if defined(DM_ABLATE) && (DM_ABLATE & 2)
+    if (g + 2 < G && p.B < 0) load_b(g + 2, br_free);
+#else
+    if (g + 2 < G) load_b(g + 2, br_free);
+#endif
+    const char* sBc = sB + (g & 1) * B_STAGE;
 #pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-          const int piece = tid + i * 256;
-          if (piece < B_PIECES) breg[i] = *reinterpret_cast<const u32x4*>(stage_src(s + 1, piece));
-        }
-      }
-      const char* sBc = sB + (s & 1) * B_STAGE;
+    for (int ksl = 0; ksl < KSPS; ++ksl) {
+      const int tap = (KSPS == 2) ? s : (s >> 1);
+      const int ks = (KSPS == 2) ? ksl : (s & 1);
+      const int kh = (TAPS == 9) ? (tap * 11) >> 5 : 0;  // tap / 3 for tap < 9
+      const int kw = (TAPS == 9) ? tap - 3 * kh : 0;
+      const int tapoff = (kh * PITCH + kw) * STRIDE + ks * 64;
+      bf16x8 av[MT], bv[NT];
 #pragma unroll
-      for (int ksl = 0; ksl < KSPS; ++ksl) {
-        const int tap = (KSPS == 2) ? s : (s >> 1);
-        const int ks = (KSPS == 2) ? ksl : (s & 1);
-        const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
-        const int tapoff = (kh * PITCH + kw) * STRIDE + ks * 64;
-        bf16x8 av[MT], bv[NT];
+      for (int mt = 0; mt < MT; ++mt)
+        av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
+      for (int nt = 0; nt < NT; ++nt)
+        bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt], av[mt], acc[mt][nt], 0, 0, 0);
-      }
-      if (s + 1 < NS) {
-        char* sBn = sB + ((s + 1) & 1) * B_STAGE;
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-          const int piece = tid + i * 256;
-          if (piece < B_PIECES) *reinterpret_cast<u32x4*>(sBn + piece * 16) = breg[i];
-        }
-      }
-      __syncthreads();
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt], av[mt], acc[mt][nt], 0, 0, 0);
     }
+    ++s;
+    if (s == NS && cc + 1 < ncc) {
+      // chunk boundary: fetch the next patch, retire the current one, swap
+      u32x4 pa[NPA];
+      load_patch(cc + 1, pa);
+      __syncthreads();
+      store_patch(pa);
+      s = 0; ++cc;
+    }
+    if (g + 1 < G) store_b((g + 1) & 1, br_next);
+    __syncthreads();
+  };
+  for (int g = 0; g < G; g += 2) {
+    step(g, br0, br1);
+    if (g + 1 < G) step(g + 1, br1, br0);
   }
 
   // ---- epilogue: lane holds couts [cq..cq+3] of pixel (lane&15) of each m-tile
