@@ -13,8 +13,8 @@
 // in 144 accumulator registers per lane, and sweeps a strided subset of the spatial tiles
 // (split-K).  The input patch (with halo) is staged once per tile and re-read for all 9 taps.
 // Partials go to a per-workgroup fp32 slab in fragment order (16-byte coalesced stores); a
-// second kernel reduces the slabs in fixed order (bit-reproducible, no atomics) and
-// accumulates into the fp32 gradient in the reference's OIHW layout.  The bias gradient
+// second kernel sums the slabs (split-K range cut into a few groups, one fp32 atomic per group and
+// element) into the fp32 gradient in the reference's OIHW layout.  The bias gradient
 // rides along as one extra MFMA per k-step against an all-ones operand.
 //
 // Reference semantics replaced: autograd's weight/bias gradients of nn.Conv2d / nn.Linear
@@ -86,7 +86,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     xo[h] = 0;  // filled per k-step (depends on row/col)
   }
 
-  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+  // Staging is software-pipelined over the tiles this workgroup sweeps: the x patch and dy tile of
+  // the NEXT tile are fetched into registers (all loads in flight together) while the MFMAs of the
+  // current tile run, and written to LDS after the barrier that retires the current images.
+  constexpr int X_PIECES = PH * PW * 8;
+  constexpr int NPX = (X_PIECES + 255) / 256;
+  constexpr int NPD = (NPIX * 8 + 255) / 256;
+  static_assert((NPIX * 8) % 256 == 0, "dy tile pieces must divide evenly over the workgroup");
+
+  auto load_tile = [&](int tile, u32x4(&px)[NPX], u32x4(&pd)[NPD], bool do_x, bool do_d) {
     int b = 0, h0 = 0, w0 = 0;
     long m0 = 0;
     if constexpr (MODE == WM_GEMM) {
@@ -100,47 +108,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     const int vh0 = (MODE == WM_S2) ? 2 * h0 - 1 : h0 - 1;
     const int vw0 = (MODE == WM_S2) ? 2 * w0 - 1 : w0 - 1;
-    __syncthreads();
-    // ---- stage x patch (64 channels of this ci tile)
-    for (int idx = tid; idx < PH * PW * 8; idx += 256) {
+    if (do_x)
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int idx = tid + i * 256;
       const int piece = idx & 7;
       const int pix = idx >> 3;
       const int pr = pix / PW, pc = pix % PW;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      bool valid;
+      bool valid = idx < X_PIECES;
       long src;
       const int ch = cit * 64 + piece * 8;
       if constexpr (MODE == WM_GEMM) {
         const long m = m0 + pix;
-        valid = (m < p.M) && (ch < p.Cin);
+        valid = valid && (m < p.M) && (ch < p.Cin);
         src = m * p.ldx + ch;
       } else {
         const int vh = vh0 + pr, vw = vw0 + pc;
         int sh = vh, sw = vw;
         if constexpr (MODE == WM_UP) {
-          valid = (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
           sh = vh >> 1; sw = vw >> 1;
         } else {
-          valid = (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+          valid = valid && (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
         }
         src = (((long)b * p.Hi + sh) * p.Wi + sw) * p.ldx + ch;
       }
-      if (valid) {
-        v = *reinterpret_cast<const u32x4*>(p.x + src);
-        if (p.act_silu_in) {
-          bf16x8 h = __builtin_bit_cast(bf16x8, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
-          v = __builtin_bit_cast(u32x4, h);
-        }
-      }
-      *reinterpret_cast<u32x4*>(sX + (pr * XPITCH + pc) * XSTRIDE + piece * 16) = v;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (valid ? src : 0));  // offset 0 is readable
+      px[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
     }
-    // ---- stage dy tile (64 channels of this co tile)
-    for (int idx = tid; idx < NPIX * 8; idx += 256) {
+    if (do_d)
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) {
+      const int idx = tid + i * 256;
       const int piece = idx & 7;
       const int q = idx >> 3;
-      u32x4 v = {0u, 0u, 0u, 0u};
       const int ch = cot * 64 + piece * 8;
       long src;
       bool valid = ch < p.Cout;
@@ -153,10 +154,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         valid = valid && (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile overhangs the image
         src = (((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c)) * p.lddy + ch;
       }
-      if (valid) v = *reinterpret_cast<const u32x4*>(p.dy + src);
-      *reinterpret_cast<u32x4*>(sD + q * DYS + piece * 16) = v;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p.dy + (valid ? src : 0));
+      pd[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_tile = [&](u32x4(&px)[NPX], u32x4(&pd)[NPD], bool do_x, bool do_d) {
+    if (do_x)
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int idx = tid + i * 256;
+      const int piece = idx & 7;
+      const int pix = idx >> 3;
+      const int pr = pix / PW, pc = pix % PW;
+      u32x4 v = px[i];
+      if (p.act_silu_in) {
+        bf16x8 h = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (bf16)dm_silu((float)h[j]);
+        v = __builtin_bit_cast(u32x4, h);
+      }
+      if (X_PIECES % 256 == 0 || idx < X_PIECES)
+        *reinterpret_cast<u32x4*>(sX + (pr * XPITCH + pc) * XSTRIDE + piece * 16) = v;
+    }
+    if (do_d)
+#pragma unroll
+    for (int i = 0; i < NPD; ++i) {
+      const int idx = tid + i * 256;
+      *reinterpret_cast<u32x4*>(sD + (idx >> 3) * DYS + (idx & 7) * 16) = pd[i];
+    }
+  };
+
+  // The prefetch registers stay live across the MFMA phase; tile shapes whose images need more than
+  // 40 of them would spill next to the 160 accumulators, so those fetch (batched) right before the write.
+  constexpr bool PREFETCH = (NPX + NPD) <= 10;
+  u32x4 px[NPX], pd[NPD];
+  if (PREFETCH && split < p.ntiles) load_tile(split, px, pd, true, true);
+  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    __syncthreads();
+    if constexpr (PREFETCH) {
+      store_tile(px, pd, true, true);
+    } else {
+      load_tile(tile, px, pd, true, false);
+      store_tile(px, pd, true, false);
+      load_tile(tile, px, pd, false, true);
+      store_tile(px, pd, false, true);
     }
     __syncthreads();
+    if (PREFETCH && tile + p.nsplit < p.ntiles) load_tile(tile + p.nsplit, px, pd, true, true);
 
 #pragma unroll 1
     for (int ksi = 0; ksi < KSTEPS; ++ksi) {
