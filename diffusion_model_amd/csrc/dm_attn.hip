@@ -59,21 +59,25 @@ __device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, long 
   if (!tok_ok || 8 * g >= hd) return zero8();
   return *reinterpret_cast<const bf16x8*>(base + tok * ld + hoff + 8 * g);
 }
-// stage 64 rows x 32 (padded) head-dim of one head into LDS; rows >= n_rows and dims >= hd are zero
-__device__ __forceinline__ void stage_block(char* dst, const bf16* base, long ld, long tok0, long n_tok, int hoff,
-                                            int hd, int tid) {
+// One 64-row x 32 (padded) head-dim block of one head travels global -> registers -> LDS, one 16-byte
+// piece per thread; rows >= n_tok and dims >= hd are zero.  The load is unconditional (offset 0 is
+// always readable) so it can stay in flight across a whole compute phase (software pipelining).
+__device__ __forceinline__ u32x4 load_piece(const bf16* base, long ld, long tok0, long n_tok, int hoff, int hd,
+                                            int tid) {
   const int row = tid >> 2, pc = tid & 3;
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (tok0 + row < n_tok && pc * 8 < hd)
-    v = *reinterpret_cast<const u32x4*>(base + (tok0 + row) * ld + hoff + pc * 8);
-  *reinterpret_cast<u32x4*>(dst + row * RS + pc * 16) = v;
+  const bool ok = (tok0 + row < n_tok) && (pc * 8 < hd);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? (tok0 + row) * ld + hoff + pc * 8 : 0));
+  return ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+__device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
+  *reinterpret_cast<u32x4*>(dst + (tid >> 2) * RS + (tid & 3) * 16) = v;
 }
 
 // ---------------------------------------------------------------- forward
 template <int DT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) char sV[64 * RS];
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -95,11 +99,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkb = (p.Nk + 63) / 64;
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();
-    stage_block(sK, p.k, p.ldk, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
-    stage_block(sV, p.v, p.ldv, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
-    __syncthreads();
+  // K/V blocks are prefetched two blocks ahead into registers and one block ahead into the other LDS
+  // buffer: one barrier per key block, no exposed global latency.
+  u32x4 rk0, rv0, rk1 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
+  rk0 = load_piece(p.k, p.ldk, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  rv0 = load_piece(p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  if (nkb > 1) {
+    rk1 = load_piece(p.k, p.ldk, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+    rv1 = load_piece(p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  }
+  store_piece(sKb[0], tid, rk0);
+  store_piece(sVb[0], tid, rv0);
+  __syncthreads();
+  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    if (kb + 2 < nkb) {
+      rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+      rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+    }
+    const char* sK = sKb[kb & 1];
+    const char* sV = sVb[kb & 1];
     f32x4 st[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][qt][r], c, -mn));
           ps += pv;
-          if (p.thresh) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv * p.inv_keep : 0.f;
+          if (p.thresh) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv : 0.f;
           st[kt][qt][r] = pv;
         }
       }
@@ -165,13 +183,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                                                                 acc[dt][qt], 0, 0, 0);
       }
     }
+    if (kb + 1 < nkb) {
+      store_piece(sKb[(kb + 1) & 1], tid, rk_next);
+      store_piece(sVb[(kb + 1) & 1], tid, rv_next);
+    }
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {
+    block(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
-    const float inv = 1.f / lt;
+    const float inv = (p.thresh ? p.inv_keep : 1.f) / lt;  // the dropout rescale rides in the normalisation
     if (qi[qt] < p.Nq) {
       if (g == 0 && p.lse) p.lse[(long)bh * p.Nq + qi[qt]] = (m[qt] + log2f(lt)) * LN2;
 #pragma unroll
@@ -211,10 +238,10 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 
 // dK, dV: one wave = 16 keys (MFMA columns), workgroup = 64 keys, loop over query blocks of 64.
 template <int DT>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char sQ[64 * RS];
-  __shared__ __attribute__((aligned(16))) char sO[64 * RS];
-  __shared__ float sL[64], sD[64];
+__global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
+  __shared__ float sLb[2][64], sDb[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int key = blockIdx.x * 64 + wave * 16 + li;
@@ -228,17 +255,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
   for (int dt = 0; dt < DT; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Nq + 63) / 64;
-  for (int qb = 0; qb < nqb; ++qb) {
-    __syncthreads();
-    stage_block(sQ, p.q, p.ldq, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
-    stage_block(sO, p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
-    if (tid < 64) {
-      const int q = qb * 64 + tid;
-      sL[tid] = (q < p.Nq) ? p.lse[(long)bh * p.Nq + q] * LOG2E : 1e30f;  // out-of-range query: p = exp2(-huge) = 0
-      sD[tid] = (q < p.Nq) ? p.delta[(long)bh * p.Nq + q] : 0.f;
-    }
-    __syncthreads();
+  // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
+  struct Regs { u32x4 q, o; float l, d; };
+  auto fetch = [&](int qb, Regs& r) {
+    r.q = load_piece(p.q, p.ldq, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
+    r.o = load_piece(p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
+    const int q = qb * 64 + (tid & 63);
+    const bool ok = q < p.Nq;
+    const long li_ = (long)bh * p.Nq + (ok ? q : 0);
+    const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
+    r.l = ok ? lv : 1e30f;  // out-of-range query: p = exp2(-huge) = 0
+    r.d = ok ? dv : 0.f;
+  };
+  auto put = [&](int buf, const Regs& r) {
+    store_piece(sQb[buf], tid, r.q);
+    store_piece(sOb[buf], tid, r.o);
+    if (tid < 64) { sLb[buf][tid] = r.l; sDb[buf][tid] = r.d; }
+  };
+  Regs r0, r1;
+  fetch(0, r0);
+  if (nqb > 1) fetch(1, r1); else r1 = r0;
+  put(0, r0);
+  __syncthreads();
+  auto block = [&](int qb, Regs& r_free, const Regs& r_next) {
+    if (qb + 2 < nqb) fetch(qb + 2, r_free);
+    const char* sQ = sQb[qb & 1];
+    const char* sO = sOb[qb & 1];
+    const float* sL = sLb[qb & 1];
+    const float* sD = sDb[qb & 1];
     f32x4 pt[4], ds[4];
+    const float ikl = p.thresh ? p.inv_keep : 1.f;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + g * 16);
@@ -256,11 +302,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
         if (p.thresh) {
           const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
           const bool keep = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh);
-          pd = keep ? pv * p.inv_keep : 0.f;
-          dpv = keep ? dpv * p.inv_keep : 0.f;
+          pd = keep ? pv : 0.f;
+          dpv = keep ? dpv : 0.f;
         }
         pt[qt][r] = pd;
-        ds[qt][r] = pv * (dpv - sD[ql]);
+        ds[qt][r] = pv * __builtin_fmaf(dpv, ikl, -sD[ql]);
       }
     }
 #pragma unroll
@@ -277,7 +323,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
         dkT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsB, dkT[dt], 0, 0, 0);
       }
     }
+    if (qb + 1 < nqb) put((qb + 1) & 1, r_next);
+    __syncthreads();
+  };
+  for (int qb = 0; qb < nqb; qb += 2) {
+    block(qb, r0, r1);
+    if (qb + 1 < nqb) block(qb + 1, r1, r0);
   }
+  const float ik = p.thresh ? p.inv_keep : 1.f;  // dropout rescale of P folded into the dV epilogue
   if (key_ok) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -285,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
       if (d < p.hd) {
         bf16x4 ok, ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[dt][r] * p.scale); ov[r] = (bf16)dvT[dt][r]; }
+        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[dt][r] * p.scale); ov[r] = (bf16)(dvT[dt][r] * ik); }
         *reinterpret_cast<bf16x4*>(p.dk + (kbase + key) * p.lddk + hoff + d) = ok;
         *reinterpret_cast<bf16x4*>(p.dv + (kbase + key) * p.lddv + hoff + d) = ov;
       }
@@ -295,9 +348,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnParams p) {
 
 // dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
 template <int DT>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char sK[64 * RS];
-  __shared__ __attribute__((aligned(16))) char sV[64 * RS];
+__global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -321,11 +374,24 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) dqT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nkb = (p.Nk + 63) / 64;
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();
-    stage_block(sK, p.k, p.ldk, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
-    stage_block(sV, p.v, p.ldv, kbase + kb * 64, kbase + p.Nk, hoff, p.hd, tid);
-    __syncthreads();
+  u32x4 rk0, rv0, rk1 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
+  rk0 = load_piece(p.k, p.ldk, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  rv0 = load_piece(p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  if (nkb > 1) {
+    rk1 = load_piece(p.k, p.ldk, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+    rv1 = load_piece(p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  }
+  store_piece(sKb[0], tid, rk0);
+  store_piece(sVb[0], tid, rv0);
+  __syncthreads();
+  const float ik = p.thresh ? p.inv_keep : 1.f;
+  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    if (kb + 2 < nkb) {
+      rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+      rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+    }
+    const char* sK = sKb[kb & 1];
+    const char* sV = sVb[kb & 1];
     f32x4 ds[4][2];
     const bool edge = kb * 64 + 64 > p.Nk;
 #pragma unroll
@@ -348,8 +414,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lq[qt]));
           if (edge && key >= p.Nk) pv = 0.f;  // key-range mask only in the last, partial key block
           float dpv = dp[r];
-          if (p.thresh) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv * p.inv_keep : 0.f;
-          ds[kt][qt][r] = pv * (dpv - Dq[qt]);
+          if (p.thresh) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv : 0.f;
+          ds[kt][qt][r] = pv * __builtin_fmaf(dpv, ik, -Dq[qt]);
         }
       }
     }
@@ -366,6 +432,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnParams p) {
                                                                 dqT[dt][qt], 0, 0, 0);
       }
     }
+    if (kb + 1 < nkb) {
+      store_piece(sKb[(kb + 1) & 1], tid, rk_next);
+      store_piece(sVb[(kb + 1) & 1], tid, rv_next);
+    }
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {
+    block(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {

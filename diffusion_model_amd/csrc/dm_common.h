@@ -60,16 +60,17 @@ __device__ __forceinline__ uint32_t dm_drop_row(uint32_t seed, uint32_t row) {
   return x;
 }
 __device__ __forceinline__ uint32_t dm_drop_bits(uint32_t rowstate, uint32_t pair) {
-  uint32_t x = rowstate + pair * 0x846CA68Bu;
-  x ^= x >> 15;
-  x *= 0x2C1B3C6Du;
-  x ^= x >> 12;
-  x *= 0x297A2D39u;
+  // Weyl step + one multiply/xorshift round: v_mul_lo_u32 is quarter rate, and these bits are drawn once
+  // per two score elements inside the exp-bound attention loops
+  uint32_t x = rowstate + pair * 0x9E3779B9u;
+  x ^= x >> 16;
+  x *= 0x21F0AAADu;
   x ^= x >> 15;
   return x;
 }
 __device__ __forceinline__ bool dm_keep16(uint32_t bits32, uint32_t col, uint32_t thresh16) {
-  return ((col & 1u) ? (bits32 >> 16) : (bits32 & 0xFFFFu)) >= thresh16;
+  // 16-bit field (col & 1) of bits32 >= thresh16, compared in the high half (no field extraction)
+  return ((col & 1u) ? bits32 : (bits32 << 16)) >= (thresh16 << 16);
 }
 // host side of the same convention
 static inline uint32_t dm_thresh16(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
