@@ -241,7 +241,8 @@ template <int DT>
 __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
-  __shared__ float sLb[2][64], sDb[2][64];
+  __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];
+  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][64];  // per-query dropout row state
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int key = blockIdx.x * 64 + wave * 16 + li;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
 
   const int nqb = (p.Nq + 63) / 64;
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
-  struct Regs { u32x4 q, o; float l, d; };
+  struct Regs { u32x4 q, o; float l, d; uint32_t rs; };
   auto fetch = [&](int qb, Regs& r) {
     r.q = load_piece(p.q, p.ldq, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
     r.o = load_piece(p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
@@ -266,11 +267,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
     r.l = ok ? lv : 1e30f;  // out-of-range query: p = exp2(-huge) = 0
     r.d = ok ? dv : 0.f;
+    r.rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
   };
   auto put = [&](int buf, const Regs& r) {
     store_piece(sQb[buf], tid, r.q);
     store_piece(sOb[buf], tid, r.o);
-    if (tid < 64) { sLb[buf][tid] = r.l; sDb[buf][tid] = r.d; }
+    if (tid < 64) { sLb[buf][tid] = r.l; sDb[buf][tid] = r.d; sRb[buf][tid] = r.rs; }
   };
   Regs r0, r1;
   fetch(0, r0);
@@ -285,28 +287,45 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     const float* sD = sDb[qb & 1];
     f32x4 pt[4], ds[4];
     const float ikl = p.thresh ? p.inv_keep : 1.f;
+    // Dropout bits: a lane holds ONE key and 16 queries per block, its neighbour (li ^ 1) the other key
+    // of the same 16-bit pair -> each of the two hashes half of the (query, pair) words and they swap
+    // through DPP.  Row states come precomputed per query from LDS.
+    uint32_t hb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, ho[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    const bool odd = (li & 1) != 0;
+    if (p.thresh) {
+      const uint32_t pk = dm_drop_pairkey((uint32_t)key >> 1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const u32x4 r4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + ((odd ? 2 : 0) + a) * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hb[a][r] = dm_drop_mix(r4[r] + pk);
+          ho[a][r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb[a][r], 0xB1, 0xF, 0xF, false);  // lane ^ 1
+        }
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + g * 16);
       const bf16x8 da = *reinterpret_cast<const bf16x8*>(sO + (qt * 16 + li) * RS + g * 16);
       const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(sL + qt * 16 + 4 * g);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(sD + qt * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = qt * 16 + 4 * g + r;
-        const int q = qb * 64 + ql;
         // no per-element masks: invalid queries carry L = +1e30 (p = 0); invalid keys only pollute their
         // own (never stored) dK/dV columns
-        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -sL[ql]));
+        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L4[r]));
         float pd = pv, dpv = dp[r];
         if (p.thresh) {
-          const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
-          const bool keep = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh);
+          const bool mine = ((qt >> 1) != 0) == odd;
+          const bool keep = dm_keep16(mine ? hb[qt & 1][r] : ho[qt & 1][r], (uint32_t)key, p.thresh);
           pd = keep ? pv : 0.f;
           dpv = keep ? dpv : 0.f;
         }
         pt[qt][r] = pd;
-        ds[qt][r] = pv * __builtin_fmaf(dpv, ikl, -sD[ql]);
+        ds[qt][r] = pv * __builtin_fmaf(dpv, ikl, -D4[r]);
       }
     }
 #pragma unroll

@@ -59,14 +59,17 @@ __device__ __forceinline__ uint32_t dm_drop_row(uint32_t seed, uint32_t row) {
   x *= 0x7FEB352Du;
   return x;
 }
-__device__ __forceinline__ uint32_t dm_drop_bits(uint32_t rowstate, uint32_t pair) {
-  // Weyl step + one multiply/xorshift round: v_mul_lo_u32 is quarter rate, and these bits are drawn once
-  // per two score elements inside the exp-bound attention loops
-  uint32_t x = rowstate + pair * 0x9E3779B9u;
+__device__ __forceinline__ uint32_t dm_drop_mix(uint32_t x) {
+  // one multiply/xorshift round: v_mul_lo_u32 is quarter rate, and these bits are drawn once per two
+  // score elements inside the exp-bound attention loops
   x ^= x >> 16;
   x *= 0x21F0AAADu;
   x ^= x >> 15;
   return x;
+}
+__device__ __forceinline__ uint32_t dm_drop_pairkey(uint32_t pair) { return pair * 0x9E3779B9u; }  // Weyl step
+__device__ __forceinline__ uint32_t dm_drop_bits(uint32_t rowstate, uint32_t pair) {
+  return dm_drop_mix(rowstate + dm_drop_pairkey(pair));
 }
 __device__ __forceinline__ bool dm_keep16(uint32_t bits32, uint32_t col, uint32_t thresh16) {
   // 16-bit field (col & 1) of bits32 >= thresh16, compared in the high half (no field extraction)
