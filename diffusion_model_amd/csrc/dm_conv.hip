@@ -46,6 +46,85 @@ struct ConvParams {
   uint32_t drop_seed; uint32_t drop_thresh; float drop_scale;  // dm_common.h dropout convention
 };
 
+// Epilogue shared by the conv and the streaming GEMM kernels: lane holds couts [cq..cq+3] of pixel
+// (lane & 15) of each of its wave's m-tiles.
+template <int MT, int NT, int TW, int MODE>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MT][NT], int nb, int wave, int lane,
+                                              int b, int h0, int w0, long m0) {
+  const int cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (nb * NT + nt) * 16 + cq;
+    if (co >= p.n_valid) continue;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+    if (p.pool2) {
+      if constexpr (MODE != MODE_GEMM && TW == 16 && (MT % 2) == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt += 2) {
+          f32x4 v = acc[mt][nt] + acc[mt + 1][nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], 1, 64);
+          const int r = wave * MT + mt;  // even output row of the pair
+          if ((lane & 1) == 0 && (h0 + r) < p.Ho && (w0 + (lane & 15)) < p.Wo) {
+            const int oh = (h0 + r) >> 1, ow = (w0 + (lane & 15)) >> 1;
+            const long pix = ((long)b * (p.Ho >> 1) + oh) * (p.Wo >> 1) + ow;
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)(v[j] + bias4[j]);
+            *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int q = (wave * MT + mt) * 16 + (lane & 15);
+      long pix;
+      int bb = b;
+      if constexpr (MODE == MODE_GEMM) {
+        pix = m0 + q;
+        if (pix >= p.M) continue;
+        bb = (int)(pix / p.rows_per_batch);
+      } else {
+        const int r = q / TW, c = q % TW;
+        if (h0 + r >= p.Ho || w0 + c >= p.Wo) continue;  // tile overhangs the image
+        pix = ((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c);
+      }
+      f32x4 v = acc[mt][nt] + bias4;
+      if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
+      if (p.drop_thresh) {
+        const uint32_t rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
+        const uint32_t b0 = dm_drop_bits(rs, (uint32_t)co >> 1), b1 = dm_drop_bits(rs, ((uint32_t)co >> 1) + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = dm_keep16(j < 2 ? b0 : b1, (uint32_t)j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+      }
+      if (p.res) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+      }
+      if (p.yf) {
+        if (co + 3 < p.n_valid) {
+          *reinterpret_cast<f32x4*>(p.yf + pix * p.ldyf + co) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co + j < p.n_valid) p.yf[pix * p.ldyf + co + j] = v[j];
+        }
+      }
+      if (p.y) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
+      }
+    }
+  }
+}
+
 template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   constexpr int TAPS = (MODE == MODE_GEMM) ? 1 : 9;
@@ -236,79 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     if (g + 1 < G) step(g + 1, br1, br0);
   }
 
-  // ---- epilogue: lane holds couts [cq..cq+3] of pixel (lane&15) of each m-tile
-  const int cq = (lane >> 4) * 4;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = (nb * NT + nt) * 16 + cq;
-    if (co >= p.n_valid) continue;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-    if (p.pool2) {
-      if constexpr (MODE != MODE_GEMM && TW == 16 && (MT % 2) == 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; mt += 2) {
-          f32x4 v = acc[mt][nt] + acc[mt + 1][nt];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], 1, 64);
-          const int r = wave * MT + mt;  // even output row of the pair
-          if ((lane & 1) == 0 && (h0 + r) < p.Ho && (w0 + (lane & 15)) < p.Wo) {
-            const int oh = (h0 + r) >> 1, ow = (w0 + (lane & 15)) >> 1;
-            const long pix = ((long)b * (p.Ho >> 1) + oh) * (p.Wo >> 1) + ow;
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)(v[j] + bias4[j]);
-            *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
-          }
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int q = (wave * MT + mt) * 16 + (lane & 15);
-      long pix;
-      int bb = b;
-      if constexpr (MODE == MODE_GEMM) {
-        pix = m0 + q;
-        if (pix >= p.M) continue;
-        bb = (int)(pix / p.rows_per_batch);
-      } else {
-        const int r = q / TW, c = q % TW;
-        if (h0 + r >= p.Ho || w0 + c >= p.Wo) continue;  // tile overhangs the image
-        pix = ((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c);
-      }
-      f32x4 v = acc[mt][nt] + bias4;
-      if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
-      if (p.drop_thresh) {
-        const uint32_t rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
-        const uint32_t b0 = dm_drop_bits(rs, (uint32_t)co >> 1), b1 = dm_drop_bits(rs, ((uint32_t)co >> 1) + 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          v[j] = dm_keep16(j < 2 ? b0 : b1, (uint32_t)j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
-      }
-      if (p.res) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-      }
-      if (p.yf) {
-        if (co + 3 < p.n_valid) {
-          *reinterpret_cast<f32x4*>(p.yf + pix * p.ldyf + co) = v;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (co + j < p.n_valid) p.yf[pix * p.ldyf + co + j] = v[j];
-        }
-      }
-      if (p.y) {
-        bf16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-        *reinterpret_cast<bf16x4*>(p.y + pix * p.ldy + co) = o;
-      }
-    }
-  }
+  conv_epilogue<MT, NT, TW, MODE>(p, acc, nb, wave, lane, b, h0, w0, m0);
 }
 
 template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
@@ -331,6 +338,121 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k, grid, dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
   return DM_OK;
+}
+
+// ------------------------------------------------------------------ streaming GEMM (1x1 conv / linear)
+// Y[M, N] = X[M, K] W^T with K <= 512: HBM-bound (X read once, Y written once), so the kernel is built
+// around the memory stream, not the MFMA pipe:
+//   * the workgroup's weight slice (all NKS k-steps of its 16*NT columns) is copied to LDS once and is
+//     read-only afterwards -> no barrier in the main loop, the four waves run decoupled;
+//   * every wave walks its own 16*MT-row tiles (global wave id, + total waves, ...) and loads the X
+//     fragments straight from global memory in MFMA operand layout (16 rows x 64 B per load; the two
+//     halves of a 128-byte line are fetched by consecutive loads), one whole tile ahead of the MFMAs;
+//   * the epilogue (bias / time-embedding / residual / fp32 out) is the conv kernel's.
+template <int MT, int NT, int NKS>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char sW[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.y;
+  const int NTG = p.Cout >> 4;
+  const int nwaves = gridDim.x * 4;
+  const int nks_real = ((p.Cin + 63) >> 6) * 2;
+  const int row_l = lane & 15, kq = (lane >> 4) * 8;
+
+  auto load_x = [&](int tile, bf16x8(&xa)[MT][NKS]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long m = ((long)tile * MT + mt) * 16 + row_l;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int ch = ks * 32 + kq;
+        const bool valid = (m < p.M) && (ch < p.Cin);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x + (valid ? m * p.ldx + ch : 0));
+        xa[mt][ks] = valid ? v : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+      }
+    }
+  };
+
+  bf16x8 xa0[MT][NKS], xa1[MT][NKS];
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) load_x(tile, xa0);
+  // weight slice: k-step ks holds NT KiB at ((ks * NTG + nb * NT) * 64) * 16
+  for (int i = tid; i < NKS * NT * 64; i += 256) {
+    const int ks = i / (NT * 64), rem = i - ks * (NT * 64);
+    u32x4 v = {0u, 0u, 0u, 0u};  // k-steps past the packed K (NKS is rounded up to 2/4/8/16) must be 0, not garbage
+    if (ks < nks_real) v = *reinterpret_cast<const u32x4*>(p.w + (((long)ks * NTG + nb * NT) * 64 + rem) * 16);
+    *reinterpret_cast<u32x4*>(sW + (long)i * 16) = v;
+  }
+  __syncthreads();
+
+  auto work = [&](int t, bf16x8(&xa)[MT][NKS], bf16x8(&xn)[MT][NKS]) {
+    if (t + nwaves < ntiles) load_x(t + nwaves, xn);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      bf16x8 bv[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bv[nt] = *reinterpret_cast<const bf16x8*>(sW + ((ks * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 av = xa[mt][ks];
+        if (p.act_silu_in) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) av[e] = (bf16)dm_silu((float)av[e]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt], av, acc[mt][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the weight fragments of later k-steps out of registers
+    }
+    conv_epilogue<MT, NT, 16, MODE_GEMM>(p, acc, nb, 0, lane, 0, 0, 0, (long)t * MT * 16);
+  };
+  for (; tile < ntiles; tile += 2 * nwaves) {
+    work(tile, xa0, xa1);
+    if (tile + nwaves < ntiles) work(tile + nwaves, xa1, xa0);
+  }
+}
+
+template <int MT, int NT, int NKS>
+int launch_gemm_stream(const ConvParams& p, hipStream_t st) {
+  constexpr int LDS = NKS * NT * 1024;
+  static_assert(LDS <= 64 * 1024, "two workgroups per CU");
+  auto k = gemm_stream_kernel<MT, NT, NKS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int ntiles = (int)((p.M + 16 * MT - 1) / (16 * MT));  // wave tiles
+  const int gy = p.Cout / (16 * NT);
+  int gx = 1024 / gy;  // up to four resident workgroups per CU in total (VGPR/LDS permitting)
+  if (gx < 1) gx = 1;
+  if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+  hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), LDS, st, p, ntiles);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+template <int NT>
+int dispatch_gemm_stream(const ConvParams& p, hipStream_t st) {
+  const int nks = ((p.Cin + 63) / 64) * 2;
+  const bool big = p.M >= 262144;  // enough rows for 32-row wave tiles to balance over the CUs
+  if (nks <= 2) return big ? launch_gemm_stream<2, NT, 2>(p, st) : launch_gemm_stream<1, NT, 2>(p, st);
+  if (nks <= 4) return big ? launch_gemm_stream<2, NT, 4>(p, st) : launch_gemm_stream<1, NT, 4>(p, st);
+  if constexpr (NT <= 4) {
+    if (nks <= 8) return big ? launch_gemm_stream<2, NT, 8>(p, st) : launch_gemm_stream<1, NT, 8>(p, st);
+    if (nks <= 16) return launch_gemm_stream<1, NT, 16>(p, st);
+  } else {
+    if (nks <= 8) return launch_gemm_stream<1, NT, 8>(p, st);
+  }
+  return 1;  // not handled here
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -456,6 +578,14 @@ extern "C" int dm_gemm(const dm_gemm_args* a, dm_stream_t stream) {
   p.act_silu_in = a->act_silu_in;
   p.drop_thresh = 0; p.drop_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
+  {
+    // streaming kernel whenever the workgroup's weight slice fits in 64 KiB of LDS
+    const int nks = ((a->K + 63) / 64) * 2;
+    int rc = 1;
+    if (a->N % 128 == 0 && nks <= 8 && a->M > 4096) rc = dispatch_gemm_stream<8>(p, st);
+    else if (a->N % 64 == 0 && nks <= 16) rc = dispatch_gemm_stream<4>(p, st);
+    if (rc <= 0) return rc;
+  }
   if (a->N % 128 == 0) return launch_conv<16, 16, 1, 16, 160, 8, MODE_GEMM>(p, st);
   if (a->N % 64 == 0) return launch_conv<16, 16, 1, 16, 160, 4, MODE_GEMM>(p, st);
   if (a->N % 32 == 0) return launch_conv<16, 16, 1, 16, 160, 2, MODE_GEMM>(p, st);
