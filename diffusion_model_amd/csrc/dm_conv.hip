@@ -377,11 +377,24 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p,
   int tile = blockIdx.x * 4 + wave;
   if (tile < ntiles) load_x(tile, xa0);
   // weight slice: k-step ks holds NT KiB at ((ks * NTG + nb * NT) * 64) * 16
-  for (int i = tid; i < NKS * NT * 64; i += 256) {
-    const int ks = i / (NT * 64), rem = i - ks * (NT * 64);
-    u32x4 v = {0u, 0u, 0u, 0u};  // k-steps past the packed K (NKS is rounded up to 2/4/8/16) must be 0, not garbage
-    if (ks < nks_real) v = *reinterpret_cast<const u32x4*>(p.w + (((long)ks * NTG + nb * NT) * 64 + rem) * 16);
-    *reinterpret_cast<u32x4*>(sW + (long)i * 16) = v;
+  {
+    constexpr int WP = NKS * NT * 64 / 256;  // 16-byte pieces per thread
+    constexpr int WB = WP < 8 ? WP : 8;      // loads kept in flight together
+#pragma unroll 1
+    for (int i0 = 0; i0 < WP; i0 += WB) {
+      u32x4 wv[WB];
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int i = tid + (i0 + u) * 256;
+        const int ks = i / (NT * 64), rem = i - ks * (NT * 64);
+        // k-steps past the packed K (NKS is rounded up to 2/4/8/16) must read as 0, not as whatever follows
+        const bool ok = ks < nks_real;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p.w + (ok ? (((long)ks * NTG + nb * NT) * 64 + rem) * 16 : 0));
+        wv[u] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < WB; ++u) *reinterpret_cast<u32x4*>(sW + (long)(tid + (i0 + u) * 256) * 16) = wv[u];
+    }
   }
   __syncthreads();
 

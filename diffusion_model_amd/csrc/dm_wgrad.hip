@@ -253,32 +253,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   // its partial into dw with one hardware fp32 atomic per element.
   const long slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
   const long per_tile = (long)taps * 4 * 4 * 256;
-  const long total = (long)ncot * ncit * per_tile;
+  const long total4 = (long)ncot * ncit * per_tile / 4;  // one thread = the 4 accumulator registers of a lane
   const int per_group = (nsplit + gridDim.y - 1) / gridDim.y;
   const int sp0 = blockIdx.y * per_group;
   const int sp1 = min(nsplit, sp0 + per_group);
   const long sp_stride = (long)ncot * ncit * slab_floats;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long tile = i / per_tile;
-    const int e = (int)(i % per_tile);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long tile = i / (per_tile / 4);
+    const int e = (int)(i % (per_tile / 4)) * 4;
     const int cot = (int)(tile / ncit), cit = (int)(tile % ncit);
-    const int reg = e & 3, lane = (e >> 2) & 63, wave = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
-    const int co = cot * 64 + t * 16 + (lane >> 4) * 4 + reg;
+    const int lane = (e >> 2) & 63, wave = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
+    const int co = cot * 64 + t * 16 + (lane >> 4) * 4;
     const int ci = cit * 64 + wave * 16 + (lane & 15);
     if (co >= Nreal || ci >= Kreal) continue;
     const float* src = slab + ((long)cot * ncit + cit) * slab_floats + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int sp = sp0;
     for (; sp + 4 <= sp1; sp += 4) {
-      s0 += src[(long)sp * sp_stride];
-      s1 += src[(long)(sp + 1) * sp_stride];
-      s2 += src[(long)(sp + 2) * sp_stride];
-      s3 += src[(long)(sp + 3) * sp_stride];
+      s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
+      s1 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 1) * sp_stride);
+      s2 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 2) * sp_stride);
+      s3 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 3) * sp_stride);
     }
-    for (; sp < sp1; ++sp) s0 += src[(long)sp * sp_stride];
-    float* dst = dw + ((long)co * Kreal + ci) * taps + tap;
-    const float s = (s0 + s1) + (s2 + s3);
-    if (gridDim.y == 1) *dst += s; else unsafeAtomicAdd(dst, s);
+    for (; sp < sp1; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
+    const f32x4 sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (co + r >= Nreal) break;
+      float* dst = dw + ((long)(co + r) * Kreal + ci) * taps + tap;
+      if (gridDim.y == 1) *dst += sum[r]; else unsafeAtomicAdd(dst, sum[r]);
+    }
   }
   if (dbias) {
     const long totalb = (long)ncot * 64;
@@ -386,12 +390,12 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   if (rc != DM_OK) return rc;
   const int Nreal = a->n_valid > 0 ? a->n_valid : a->Cout;
   const int Kreal = a->k_valid > 0 ? a->k_valid : a->Cin;
-  const long total = (long)pl.ncot * pl.ncit * a->taps * 4096;
+  const long total = (long)pl.ncot * pl.ncit * a->taps * 1024;  // float4 items
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  int groups = pl.nsplit / 8;  // every group still sums >= 8 slabs in registers
+  int groups = pl.nsplit / 16;  // every group sums >= 16 slabs in registers; few atomics per element
   if (groups < 1) groups = 1;
-  if (groups > 32) groups = 32;
+  if (groups > 8) groups = 8;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
                      pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
   DM_LAUNCH_CHECK();
