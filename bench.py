@@ -63,10 +63,10 @@ def build_model(dropout, dev):
 
 
 def time_dominant_kernel(B, dev, reps=20):
-    """Live HIP-event timing of the dominant kernel family: nearest-x2 + conv3x3 (the two largest convs,
-    36 % of forward FLOPs), on the stream it is launched on.  Returns (avg_seconds, flops_per_launch)."""
+    """Live HIP-event timing of the dominant MFMA kernel: nearest-x2 + conv3x3 at the L4.upsample.conv shape
+    (2.72 of the 18.08 forward GFLOP per image), on the stream it is launched on.  Returns (avg_seconds, flops_per_launch)."""
     from diffusion_model_amd import kernels as K
-    shapes = [(48, 128, 128), (24, 256, 256)]  # (input H=W, Cin, Cout): L4.upsample.conv, L3.upsample.conv
+    shapes = [(48, 128, 128)]  # (input H=W, Cin, Cout): L4.upsample.conv, the largest single conv of the step
     tot, flops = 0.0, 0.0
     for H, cin, cout in shapes:
         x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
@@ -231,8 +231,14 @@ def main():
         out["sampling"] = sampling
     if not a.no_roofline:
         sec, fl = time_dominant_kernel(a.batch, dev)
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # collected in separate rocprofv3 --pmc runs of the same kernel and shape; bench.py cannot run PMC itself)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_conv.json")
+        if a.batch == 64 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes"]
         out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                           "frac": fl / sec / PEAK_BF16, "traffic": None,
+                           "frac": fl / sec / PEAK_BF16, "traffic": traffic,
                            "kernel": "conv_mfma_kernel<16,16,1,18,160,8,MODE_UP> (nearest-x2 + conv3x3, B=%d)" % a.batch,
                            "avg_launch_us": sec * 1e6, "flop_per_launch": fl}
     if not a.no_cpu_baseline:
