@@ -1,0 +1,157 @@
+"""Drop-in for the reference's ``main_stl10.train()`` / ``inference()`` (main_stl10.py:352-545, 547-566) on
+the HIP hot path.  Same call signatures, same arithmetic per batch, same checkpoint dict
+(``{'weights', 'optimizer', 'ema'}``, main_stl10.py:533-539).
+
+Outside the hot path, on purpose: the torchvision STL10 reader and the matplotlib
+monitoring images.  ``train`` therefore takes the batches from a ``train_loader`` argument (any iterable
+of ``(x[B,3,96,96] in [-1,1], labels[B])`` with ``len()``; a seeded synthetic loader of the same shape is
+used when none is given), and ``inference`` returns the fixed-seed class grid as a tensor instead of
+writing PNGs.  Monitoring hooks can be attached through ``on_epoch_end``."""
+from __future__ import annotations
+
+import os
+from typing import Callable, Iterable, Optional
+
+import torch
+
+from . import config, utils
+from .ema import ModelEmaV2
+from .sampler import CFGSampler
+from .trainer import Trainer
+from .utils import DDPM_beta_t_cosine_scheduler, load_model
+
+BATCH_SIZE = config.BATCH_SIZE
+LR = config.LR
+EMA_DECAY = config.EMA_DECAY
+NUM_TIME_STEPS = config.NUM_TIME_STEPS
+CFG_SCALE = config.CFG_SCALE
+CFG_P_UNCOND = config.CFG_P_UNCOND
+SAMPLING_ETA = config.SAMPLING_ETA
+UNCOND_ID = config.UNCOND_ID
+VIRTUAL_BATCH_SIZE_MULTIPLIER = config.VIRTUAL_BATCH_SIZE_MULTIPLIER
+TOTAL_EPOCHS_NEW = config.TOTAL_EPOCHS_NEW
+START_EPOCH = config.START_EPOCH
+CLIP_TABLE_PATH = utils.CLIP_TABLE_PATH
+device = utils.device
+
+
+class SyntheticLoader:
+    """Stand-in for the STL10 DataLoader: ``n_batches`` seeded batches of clamp(N(0, 0.5^2), -1, 1) images
+    and uniform labels 0..9 (the bench's recipe)."""
+
+    def __init__(self, n_batches=8, batch_size=BATCH_SIZE, seed=1234, size=96):
+        self.n, self.bs, self.seed, self.size = n_batches, batch_size, seed, size
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(self.n):
+            x = (torch.randn(self.bs, 3, self.size, self.size, generator=g) * 0.5).clamp_(-1, 1)
+            yield x, torch.randint(0, 10, (self.bs,), generator=g)
+
+
+def _checkpoint_dict(model, trainer: Trainer, ema: ModelEmaV2) -> dict:
+    return {"weights": {k: v.detach().clone() for k, v in model.state_dict().items()},
+            "optimizer": trainer.optimizer_state_dict(),
+            "ema": {k: v.detach().clone() for k, v in ema.state_dict().items()}}
+
+
+def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train_loader: Optional[Iterable] = None,
+          total_epochs: int = TOTAL_EPOCHS_NEW, start_epoch: int = START_EPOCH, checkpoint_dir: str = ".",
+          checkpoint_every: int = 5, on_epoch_end: Optional[Callable] = None, check_finite: bool = True,
+          distributed: Optional[bool] = None, log: Callable = print):
+    """Reference main_stl10.py:352-545.  Returns ``(model, ema, trainer)``."""
+    scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
+    if train_loader is None:
+        log("[warn] no train_loader given: the STL10 reader is outside this package's scope; using SyntheticLoader")
+        train_loader = SyntheticLoader()
+    if utils.CONTEXT_TABLE is None and os.path.exists(clip_table_path):
+        utils._load_clip_context_table(clip_table_path)
+        log(f"[info] Loaded CLIP context table from {clip_table_path} with dim {utils.CONTEXT_TABLE.shape[-1]}")
+    elif utils.CONTEXT_TABLE is None:
+        log(f"[warn] CLIP table not found at {clip_table_path}; training without cross-attention context")
+    model = load_model(LDM=config.LDM, NUM_TIME_STEPS=1000, DROPOUT=config.DROPOUT).to(device)
+    ema = ModelEmaV2(model, decay=EMA_DECAY)
+
+    if checkpoint_path is not None:
+        if os.path.exists(checkpoint_path):
+            ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+            model.load_state_dict(ck["weights"])
+            try:
+                ema.load_state_dict(ck["ema"])
+            except Exception as exc:  # reference: re-initialise the EMA from the model
+                log(f"[warn] EMA state_dict load failed ({exc}); initializing EMA from model.")
+                ema.module.load_state_dict(model.state_dict())
+            log(f"Loaded checkpoint from {checkpoint_path}")
+        else:
+            log(f"Checkpoint file not found: {checkpoint_path}")
+
+    n_batches = len(train_loader)
+    accum = max(1, VIRTUAL_BATCH_SIZE_MULTIPLIER)
+    total_steps_new = total_epochs * n_batches                      # main_stl10.py:402 (counts batches)
+    steps_so_far = start_epoch * ((n_batches + accum - 1) // accum)  # main_stl10.py:441-446
+    if distributed is None:
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+    trainer = Trainer(model, scheduler, lr=LR, weight_decay=config.WEIGHT_DECAY, betas=config.BETAS,
+                      clip=config.GRAD_CLIP, ema_decay=EMA_DECAY, accum=accum, total_steps=total_steps_new,
+                      start_step=steps_so_far, ema=ema, distributed=distributed)
+    table = utils.CONTEXT_TABLE.to(device) if utils.CONTEXT_TABLE is not None else None
+
+    for epoch in range(start_epoch, total_epochs):
+        low_t = config.USING_LOW_T_REWARDING and epoch >= config.LOW_T_REWARDING_WARMUP_EPOCHS
+        trainer.low_t_weight = config.LOW_T_REWARDING_WARMUP_WEIGHT if low_t else None
+        sum_loss = torch.zeros(1, device=device)
+        model.train()
+        for i, (x, labels) in enumerate(train_loader):
+            x = x.to(device, non_blocking=True).float()
+            labels = labels.to(device)
+            drop_mask = torch.rand(labels.shape[0], device=device) < CFG_P_UNCOND   # main_stl10.py:455-457
+            labels_dropped = labels.clone()
+            labels_dropped[drop_mask] = UNCOND_ID
+            t = torch.randint(0, NUM_TIME_STEPS, (x.shape[0],)).to(device)         # drawn on the host, as :458
+            e = torch.randn_like(x)
+            context = table[labels_dropped.long()] if table is not None else None
+            do_step = ((i + 1) % accum == 0) or (i + 1 == n_batches)                # main_stl10.py:506
+            loss = trainer.micro_step(x, context, t, e, step_now=do_step, check_finite=check_finite)
+            sum_loss += loss.detach().reshape(-1)[:1]
+        log(f"Epoch {epoch + 1} | Loss {float(sum_loss.item()) / max(1, n_batches):.5f}")
+        if on_epoch_end is not None:
+            on_epoch_end(epoch + 1, model, ema, scheduler)
+        if checkpoint_every and (epoch + 1) % checkpoint_every == 0:
+            torch.save(_checkpoint_dict(model, trainer, ema),
+                       os.path.join(checkpoint_dir, f"stl10_checkpoint_epoch_{epoch + 1}.pt"))
+    return model, ema, trainer
+
+
+def generate_fixed_seed_class_grid(model, scheduler, cfg_scale: float = CFG_SCALE, eta: float = SAMPLING_ETA,
+                                   label_ids=None, base_seed: int = 42, num_time_steps: int = NUM_TIME_STEPS,
+                                   size: int = 96) -> torch.Tensor:
+    """Reference visualization.py:404-461 without the plotting: one sample per label, start noise of label i
+    drawn from seed ``base_seed + i`` (the reference seeds the global generator per label), guidance 0.0 for
+    the unconditional label (:424).  All labels run as ONE batch through the fused sampler; the per-step
+    ancestral noise comes from one device generator seeded ``base_seed`` (the reference's device RNG stream is
+    not reproducible across backends anyway).  Returns ``[len(label_ids), 3, size, size]`` in [-1, 1]."""
+    if label_ids is None:
+        label_ids = list(range(10)) + [UNCOND_ID]
+    z = torch.cat([torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(base_seed + i))
+                   for i in range(len(label_ids))]).to(device)
+    labels = torch.tensor(label_ids, device=device, dtype=torch.long)
+    gen = torch.Generator(device=device).manual_seed(base_seed)
+    sampler = CFGSampler(model, scheduler, utils.CONTEXT_TABLE.to(device), UNCOND_ID)
+    model.eval()
+    with torch.no_grad():
+        return sampler.sample(z, labels, guidance_scale=cfg_scale, eta=eta, num_time_steps=num_time_steps,
+                              generator=gen)
+
+
+def inference(checkpoint_path, label: Optional[int] = None, guidance_scale: float = CFG_SCALE,
+              clip_table_path: str = CLIP_TABLE_PATH, *, num_time_steps: int = NUM_TIME_STEPS, size: int = 96):
+    """Reference main_stl10.py:547-566: load ``weights`` and ``ema`` from the checkpoint, sample with the EMA
+    weights.  Returns the fixed-seed class grid tensor (all 11 labels, or only ``label``)."""
+    model, ema = utils.load_checkpoint(checkpoint_path, clip_table_path)
+    scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
+    ids = None if label is None else [int(label)]
+    return generate_fixed_seed_class_grid(ema.module, scheduler, cfg_scale=guidance_scale, eta=SAMPLING_ETA,
+                                          label_ids=ids, num_time_steps=num_time_steps, size=size)

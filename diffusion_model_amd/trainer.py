@@ -150,29 +150,58 @@ class Trainer:
         model._bwd_hook = None
 
     # ------------------------------------------------------------------ one micro-batch
-    def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+    def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, *,
+                   step_now: Optional[bool] = None, check_finite: bool = False) -> torch.Tensor:
         """x,e: [B,C,H,W] fp32 on the device; t: [B] long (device); context: [B,D] fp32 or None.
-        Returns the (un-synchronised) loss tensor [1]."""
+        Returns the (un-synchronised) loss tensor [1].
+        step_now overrides the accumulation gate (reference main_stl10.py:506: the last batch of an epoch
+        steps even if the accumulation window is not full); check_finite mirrors main_stl10.py:484-486
+        (a non-finite loss skips the batch before backward) at the price of one host sync."""
         B = x.shape[0]
         chw = x.numel() // B
         abar = self.scheduler.alpha_t[t].contiguous()
         xt, v = K.qsample_vtarget(x, e, abar)
         tgt = v if self.target == "v" else e
-        last = (self.micro + 1) % self.accum == 0
+        last = ((self.micro + 1) % self.accum == 0) if step_now is None else bool(step_now)
         y, saved = self.model._fwd(xt, t, context)
         if self.low_t_weight is None:
             w = torch.full((B,), 1.0 / (B * chw), dtype=torch.float32, device=x.device)
         else:
             w = torch.exp(-self.low_t_weight * t.float()) / (B * chw)
         loss, dout = K.mse_loss_fwd_bwd(y, tgt, w.contiguous(), grad_scale=1.0 / self.accum)
+        if check_finite and not bool(torch.isfinite(loss).all().item()):
+            return loss  # reference: "continue" -- no backward, no accumulation-counter change
         if self.buckets is not None and last:
             self.model._bwd_hook = self.buckets.launch
         self.model._bwd(dout, saved, self.grads)
         self.model._bwd_hook = None
-        self.micro += 1
+        self.micro = 0 if last else self.micro + 1
         if last and not self.defer_optimizer:
             self.optimizer_step()
         return loss
+
+    def optimizer_state_dict(self) -> dict:
+        """The fused optimizer's state in torch.optim.AdamW.state_dict() form (the 'optimizer' entry of
+        the reference checkpoint, main_stl10.py:533-539): per-parameter step / exp_avg / exp_avg_sq."""
+        state = {}
+        for i, (p, (o, n)) in enumerate(zip(self.fp.params, self.fp.offsets)):
+            state[i] = {"step": torch.tensor(float(self.opt_step)),
+                        "exp_avg": self.m[o:o + n].view_as(p).clone(),
+                        "exp_avg_sq": self.v[o:o + n].view_as(p).clone()}
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "initial_lr": self.lr,
+                 "params": list(range(len(self.fp.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        for i, (p, (o, n)) in enumerate(zip(self.fp.params, self.fp.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.opt_step = int(float(st["step"]))
 
     # ------------------------------------------------------------------ clip + AdamW + EMA
     def current_lr(self) -> float:

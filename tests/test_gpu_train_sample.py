@@ -168,3 +168,48 @@ def test_cfg_sampler_matches_oracle_and_reference_contract():
     # both run the same bf16 UNet; fp32 round-off differences in the step arithmetic flip a few bf16
     # roundings of the UNet input per step, so agreement is at the bf16 level, not the fp32 level
     assert_close(x0_fast, x0_ref_api, 2e-2, "fused sampler vs callback-contract sampler")
+
+
+# --------------------------------------------------------------------------- main_stl10.train() / inference()
+@pytest.mark.gpu
+def test_main_stl10_train_checkpoint_inference_roundtrip(tmp_path):
+    """Drop-in train()/inference() (reference main_stl10.py:352-566): the epoch loop with the tail-step gate,
+    the reference checkpoint dict (loadable by torch.optim.AdamW and strict state_dict loads), resume, and
+    EMA-weight sampling from the saved file."""
+    from diffusion_model_amd import main_stl10 as M, utils as U
+    from diffusion_model_amd.unet import UNET
+    logs = []
+    loader = M.SyntheticLoader(n_batches=3, batch_size=4, seed=7, size=32)   # odd count: last batch must step alone
+    model, ema, tr = M.train(None, train_loader=loader, total_epochs=22, start_epoch=20, checkpoint_dir=str(tmp_path),
+                             checkpoint_every=1, log=logs.append)
+    # 2 epochs x ceil(3/2) optimizer steps; LR scheduler fast-forwarded by start_epoch * 2
+    assert tr.opt_step == 4 and tr.sched_step == 20 * 2 + 4
+    assert any(s.startswith("Epoch 22 | Loss") for s in logs)
+    ck_path = tmp_path / "stl10_checkpoint_epoch_22.pt"
+    ck = torch.load(ck_path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"weights", "optimizer", "ema"}
+    assert list(ck["weights"]) == list(model.state_dict())
+    assert list(ck["ema"]) == ["module." + k for k in ck["weights"]]
+    # EMA really moved away from the weights and towards them by (1 - 0.995) per step
+    k0 = "input_conv.weight"
+    assert not torch.equal(ck["ema"]["module." + k0], ck["weights"][k0])
+    # the 'optimizer' entry is a torch.optim.AdamW state_dict
+    twin = UNET(input_channels=3, output_channels=3, context_dim=512)
+    twin.load_state_dict(ck["weights"], strict=True)
+    opt = torch.optim.AdamW(twin.parameters(), lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99))
+    opt.load_state_dict(ck["optimizer"])
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(twin.parameters())) and float(st[0]["step"]) == 4.0
+    assert all(torch.isfinite(v["exp_avg_sq"]).all() and (v["exp_avg_sq"] >= 0).all() for v in st.values())
+    assert sum(float(v["exp_avg"].abs().sum()) for v in st.values()) > 0
+    # resume from the file (weights + EMA), one more epoch
+    model2, ema2, tr2 = M.train(str(ck_path), train_loader=loader, total_epochs=23, start_epoch=22,
+                                checkpoint_dir=str(tmp_path), checkpoint_every=0, log=logs.append)
+    assert any(s.startswith("Loaded checkpoint") for s in logs) and tr2.opt_step == 2
+    # inference(): EMA weights, fixed seeds, one label and the full 11-label grid
+    img = M.inference(str(ck_path), label=3, guidance_scale=6.0, num_time_steps=4, size=32)
+    assert tuple(img.shape) == (1, 3, 32, 32) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
+    img2 = M.inference(str(ck_path), label=3, guidance_scale=6.0, num_time_steps=4, size=32)
+    assert torch.equal(img, img2)                      # fixed seeds => reproducible
+    grid = M.inference(str(ck_path), guidance_scale=6.0, num_time_steps=3, size=32)
+    assert tuple(grid.shape) == (11, 3, 32, 32) and torch.isfinite(grid).all()
