@@ -88,7 +88,7 @@ _SIGS = {
     "dm_sqnorm_workspace_bytes": (c_long, []),
     "dm_grad_norm_clipcoef": (c_int, [c_void_p, c_long, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_adamw_ema_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float,
-                                  c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_int, c_void_p]),
+                                  c_float, c_float, c_float, c_float, c_int, C.c_double, c_float, c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -249,7 +249,7 @@ __global__ void finish_norm_kernel(const float* __restrict__ partial, int n, flo
 }
 
 struct AdamArgs {
-  float lr, b1, b2, eps, wd, bc1, bc2_sqrt, ema_decay, pre_scale;
+  float lr, b1, b2, eps, wd, bc1, bc2_sqrt, ema_decay, ema_rest, pre_scale;
   int adamw;  // 1: decoupled decay (AdamW), 0: Adam (L2 decay folded in the gradient, wd usually 0)
 };
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -276,7 +276,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     reinterpret_cast<f32x4*>(v)[i] = vv;
     if (ema) {
       f32x4 ev = reinterpret_cast<f32x4*>(ema)[i];
-      ev = a.ema_decay * ev + (1.f - a.ema_decay) * pv;
+      ev = a.ema_decay * ev + a.ema_rest * pv;
       reinterpret_cast<f32x4*>(ema)[i] = ev;
     }
   }
@@ -406,13 +406,14 @@ extern "C" int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, flo
 
 extern "C" int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip,
                                  long n, float lr, float beta1, float beta2, float eps, float wd, int step,
-                                 float ema_decay, float pre_scale, int adamw, dm_stream_t stream) {
+                                 double ema_decay, float pre_scale, int adamw, dm_stream_t stream) {
   DM_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1);
   AdamArgs a;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = wd;
   a.bc1 = (float)(1.0 - pow((double)beta1, step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
-  a.ema_decay = ema_decay; a.pre_scale = pre_scale; a.adamw = adamw;
+  a.ema_decay = (float)ema_decay; a.ema_rest = (float)(1.0 - ema_decay);  // 1 - d in double: timm's (1.0 - decay)
+  a.pre_scale = pre_scale; a.adamw = adamw;
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, ema, clip,
                      n, a);
   DM_LAUNCH_CHECK();

@@ -205,6 +205,8 @@ class Trainer:
 
     # ------------------------------------------------------------------ clip + AdamW + EMA
     def current_lr(self) -> float:
+        if not self.total_steps:  # no LambdaLR (reference main.py:150: plain Adam at a constant rate)
+            return self.lr
         return self.lr * lr_lambda(self.sched_step, self.total_steps)
 
     def optimizer_step(self) -> None:

@@ -186,7 +186,7 @@ int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, float pre_scal
 /* Fused clip-scale + AdamW (or Adam) + EMA over a flat fp32 buffer
  * (main_stl10.py:396,509-510; main.py:152-153,181-182). clip = norm_out of the call above or NULL. */
 int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
-                      float lr, float beta1, float beta2, float eps, float wd, int step, float ema_decay,
+                      float lr, float beta1, float beta2, float eps, float wd, int step, double ema_decay,
                       float pre_scale, int adamw, dm_stream_t stream);
 
 #ifdef __cplusplus

@@ -213,3 +213,76 @@ def test_main_stl10_train_checkpoint_inference_roundtrip(tmp_path):
     assert torch.equal(img, img2)                      # fixed seeds => reproducible
     grid = M.inference(str(ck_path), guidance_scale=6.0, num_time_steps=3, size=32)
     assert tuple(grid.shape) == (11, 3, 32, 32) and torch.isfinite(grid).all()
+
+
+# --------------------------------------------------------------------------- MNIST baseline (main.py)
+def test_mnist_train_step_matches_oracle():
+    """Reference main.py:142-188 on the HIP path: 32x32x1, attention-free UNet, epsilon target, plain mean MSE,
+    clip 0.5, Adam(lr 5e-5, betas (0.9, 0.999)) at a constant rate, EMA 0.999, one step per batch."""
+    from diffusion_model_amd import main as MN
+    from diffusion_model_amd.ema import ModelEmaV2
+    from diffusion_model_amd.trainer import Trainer
+    from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+    torch.manual_seed(0)
+    from diffusion_model_amd.unet import UNET
+    # main.py:148-149 with dropout off (0.1 in the reference's MNIST model; parity needs a deterministic step)
+    model = UNET(time_steps=MN.NUM_TIME_STEPS, label_embedding=True, Attentions=[False] * 6, use_film=False,
+                 dropout_prob=0.0)
+    with torch.no_grad():
+        model.output_conv.weight.normal_(0, 0.05)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev()).train()
+    sched = DDPM_beta_t_cosine_scheduler(1000, beta_min=0.0)
+    ema = ModelEmaV2(model, decay=MN.EMA_DECAY)
+    tr = Trainer(model, sched, lr=MN.LR, weight_decay=0.0, betas=(0.9, 0.999), clip=MN.GRAD_CLIP,
+                 ema_decay=MN.EMA_DECAY, accum=1, total_steps=0, low_t_weight=None, target="e", adamw=False, ema=ema)
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    x = torch.nn.functional.pad(torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, (2, 2, 2, 2))
+    t = torch.randint(0, 1000, (B,), generator=g)
+    e = torch.randn(B, 1, 32, 32, generator=g)
+    # oracle
+    spec = oref.UNetSpec(Attentions=[False] * 6, dropout_prob=0.0)
+    sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+    names = list(sd)
+    _, _, abar = dref.cosine_schedule(1000, beta_min=0.0)
+    a = abar[t].view(-1, 1, 1, 1)
+    xt = torch.sqrt(a) * x + torch.sqrt(1 - a) * e
+    loss_ref = torch.mean((oref.unet_forward(sd, spec, xt, t, None) - e) ** 2)
+    gs = list(torch.autograd.grad(loss_ref, [sd[k] for k in names], allow_unused=True))
+    gs = [gg if gg is not None else torch.zeros_like(sd[k]) for gg, k in zip(gs, names)]
+    # HIP
+    tr.defer_optimizer = True
+    loss = tr.micro_step(x.to(dev()), None, t.to(dev()), e.to(dev()))
+    assert float(loss) == pytest.approx(float(loss_ref), rel=2e-2)
+    gmax = max(float(gg.norm()) for gg in gs)
+    hip = []
+    for p, gg, n in zip(model.parameters(), gs, names):
+        hg = tr.fp.grad_views[id(p)].detach().cpu().clone()
+        hip.append(hg)
+        if float(gg.norm()) < 1e-6 * gmax:
+            assert float(hg.norm()) < 1e-3 * gmax, n
+        else:
+            assert rel_l2(hg, gg) < 3e-2, f"{n}: gradient rel-L2 {rel_l2(hg, gg):.3e}"
+    # clip 0.5 + Adam + EMA on the HIP gradients
+    p_ref = {k: v.detach().clone() for k, v in sd0.items()}
+    e_ref = {k: v.detach().clone() for k, v in sd0.items()}
+    gl = [h.clone() for h in hip]
+    total = dref.clip_grad_norm(gl, 0.5)
+    for k, gg in zip(names, gl):
+        dref.adamw_step(p_ref[k], gg, torch.zeros_like(gg), torch.zeros_like(gg), 1, MN.LR, 0.9, 0.999, 1e-8, 0.0)
+    dref.ema_update(e_ref, p_ref, MN.EMA_DECAY)
+    tr.optimizer_step()
+    assert tr.current_lr() == MN.LR and tr.grad_norm() == pytest.approx(float(total), rel=1e-4)
+    for (k, p), (ke, pe) in zip(model.state_dict().items(), ema.state_dict().items()):
+        assert_close(p.cpu() - sd0[k], p_ref[k] - sd0[k], 1e-3, f"delta {k}", atol_frac=1e-3)
+        assert_close(pe.cpu(), e_ref[k], 1e-6, f"ema {k}", atol_frac=1e-6)
+
+
+def test_mnist_train_loop_runs():
+    from diffusion_model_amd import main as MN
+    logs = []
+    model, ema, tr = MN.train(None, train_loader=MN.SyntheticDigits(n_batches=3, batch_size=8), num_epochs=2,
+                              log=logs.append)
+    assert tr.opt_step == 6 and len(logs) == 2 and all("Loss" in s for s in logs)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
