@@ -12,7 +12,10 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libdm_hip.so")
 OBJ = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math", "-fno-gpu-rdc",
-         "-Wno-unused-result", "-DNDEBUG"]
+         "-Wno-unused-result", "-DNDEBUG",
+         # no SLP vectorizer: it pairs scalar fp32 adds/muls into v_pk_*_f32, which issue slower than the two
+         # scalar ops they replace next to MFMA/exp streams (measured on the attention kernels)
+         "-fno-slp-vectorize"]
 
 
 def hipcc():

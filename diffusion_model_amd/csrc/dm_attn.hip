@@ -15,6 +15,7 @@
 // Reference semantics replaced: F.scaled_dot_product_attention(q,k,v,dropout_p) with scale
 // 1/sqrt(hd), non-causal (unet.py:119-126,136,165-172,214) and its autograd backward.
 #include "dm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -74,7 +75,9 @@ __device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
 }
 
 // ---------------------------------------------------------------- forward
-template <int DT>
+// DROP and the edge (partial last key block) handling are compile-time: the compiler if-converts runtime
+// `if (p.thresh)` / `if (edge)` guards into unconditional hash + select code, which the eval path then pays for.
+template <int DT, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   store_piece(sKb[0], tid, rk0);
   store_piece(sVb[0], tid, rv0);
   __syncthreads();
-  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+  auto block = [&](auto edge_c, int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     if (kb + 2 < nkb) {
       rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
       rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
@@ -129,11 +133,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     // Per-element VALU budget (the bound of these small-head kernels): max, fma, v_exp, add, half a
     // cvt_pk.  The key-range mask is applied only in the last, partial key block; the softmax scale
     // rides in the fma; v_exp_f32 is issued raw (no denormal range fix-up: p < 2^-126 is 0 anyway).
-    const bool edge = kb * 64 + 64 > p.Nk;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float bm = NEG;
-      if (edge) {
+      if constexpr (EDGE) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -150,11 +153,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
       const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
       m[qt] = mn;
       float ps = 0.f;
-      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) : 0u;
+      uint32_t rs = 0u;
+      if constexpr (DROP) rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         uint32_t db0 = 0u, db1 = 0u;
-        if (p.thresh) {
+        if constexpr (DROP) {
           const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
           db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
         }
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][qt][r], c, -mn));
           ps += pv;
-          if (p.thresh) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv : 0.f;
+          if constexpr (DROP) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv : 0.f;
           st[kt][qt][r] = pv;
         }
       }
@@ -189,16 +193,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
     __syncthreads();
   };
+  const bool has_edge = (p.Nk & 63) != 0;
+  auto run = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    if (has_edge && kb == nkb - 1) block(std::true_type{}, kb, rk_free, rv_free, rk_next, rv_next);
+    else block(std::false_type{}, kb, rk_free, rv_free, rk_next, rv_next);
+  };
   for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
+    run(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) run(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
-    const float inv = (p.thresh ? p.inv_keep : 1.f) / lt;  // the dropout rescale rides in the normalisation
+    const float inv = (DROP ? p.inv_keep : 1.f) / lt;  // the dropout rescale rides in the normalisation
     if (qi[qt] < p.Nq) {
       if (g == 0 && p.lse) p.lse[(long)bh * p.Nq + qi[qt]] = (m[qt] + log2f(lt)) * LN2;
 #pragma unroll
@@ -237,7 +246,7 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 }
 
 // dK, dV: one wave = 16 keys (MFMA columns), workgroup = 64 keys, loop over query blocks of 64.
-template <int DT>
+template <int DT, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
@@ -286,13 +295,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     const float* sL = sLb[qb & 1];
     const float* sD = sDb[qb & 1];
     f32x4 pt[4], ds[4];
-    const float ikl = p.thresh ? p.inv_keep : 1.f;
+    const float ikl = DROP ? p.inv_keep : 1.f;
     // Dropout bits: a lane holds ONE key and 16 queries per block, its neighbour (li ^ 1) the other key
     // of the same 16-bit pair -> each of the two hashes half of the (query, pair) words and they swap
     // through DPP.  Row states come precomputed per query from LDS.
     uint32_t hb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, ho[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     const bool odd = (li & 1) != 0;
-    if (p.thresh) {
+    if constexpr (DROP) {
       const uint32_t pk = dm_drop_pairkey((uint32_t)key >> 1);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
         // own (never stored) dK/dV columns
         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L4[r]));
         float pd = pv, dpv = dp[r];
-        if (p.thresh) {
+        if constexpr (DROP) {
           const bool mine = ((qt >> 1) != 0) == odd;
           const bool keep = dm_keep16(mine ? hb[qt & 1][r] : ho[qt & 1][r], (uint32_t)key, p.thresh);
           pd = keep ? pv : 0.f;
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     block(qb, r0, r1);
     if (qb + 1 < nqb) block(qb + 1, r1, r0);
   }
-  const float ik = p.thresh ? p.inv_keep : 1.f;  // dropout rescale of P folded into the dV epilogue
+  const float ik = DROP ? p.inv_keep : 1.f;  // dropout rescale of P folded into the dV epilogue
   if (key_ok) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
 }
 
 // dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
-template <int DT>
+template <int DT, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
@@ -403,8 +412,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
   store_piece(sKb[0], tid, rk0);
   store_piece(sVb[0], tid, rv0);
   __syncthreads();
-  const float ik = p.thresh ? p.inv_keep : 1.f;
-  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+  const float ik = DROP ? p.inv_keep : 1.f;
+  auto block = [&](auto edge_c, int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     if (kb + 2 < nkb) {
       rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
       rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
@@ -412,7 +422,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 ds[4][2];
-    const bool edge = kb * 64 + 64 > p.Nk;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
         const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         uint32_t db0 = 0u, db1 = 0u;
-        if (p.thresh) {
+        if constexpr (DROP) {
           const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
           const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
           db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
@@ -431,12 +440,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 64 + kt * 16 + 4 * g + r;
           float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lq[qt]));
-          if (edge && key >= p.Nk) pv = 0.f;  // key-range mask only in the last, partial key block
+          if constexpr (EDGE) { if (key >= p.Nk) pv = 0.f; }  // key-range mask only in the last, partial key block
           float dpv = dp[r];
-          if (p.thresh) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv : 0.f;
+          if constexpr (DROP) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv : 0.f;
           ds[kt][qt][r] = pv * __builtin_fmaf(dpv, ik, -Dq[qt]);
         }
       }
+      // keep the 16 score / dP MFMA results of later key tiles out of registers (3 waves per SIMD)
+      if constexpr (DROP) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -457,9 +468,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
     }
     __syncthreads();
   };
+  const bool has_edge = (p.Nk & 63) != 0;
+  auto run = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
+    if (has_edge && kb == nkb - 1) block(std::true_type{}, kb, rk_free, rv_free, rk_next, rv_next);
+    else block(std::false_type{}, kb, rk_free, rv_free, rk_next, rv_next);
+  };
   for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
+    run(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) run(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -700,8 +716,13 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     return DM_OK;
   }
   const dim3 grid((p.Nq + 127) / 128, p.B * p.H);
-  if (p.hd > 16) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (p.thresh) {
+    if (p.hd > 16) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    if (p.hd > 16) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  }
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -732,15 +753,15 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
   DM_LAUNCH_CHECK();
   const dim3 gkv((p.Nk + 63) / 64, p.B * p.H), gq((p.Nq + 127) / 128, p.B * p.H);
-  if (p.hd > 16) {
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<2>, gkv, dim3(256), 0, st, p);
-    DM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_q_kernel<2>, gq, dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<1>, gkv, dim3(256), 0, st, p);
-    DM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_q_kernel<1>, gq, dim3(256), 0, st, p);
-  }
+#define DM_BWD(DT, DROP)                                                                   \
+  do {                                                                                     \
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DT, DROP>), gkv, dim3(256), 0, st, p);          \
+    DM_LAUNCH_CHECK();                                                                     \
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP>), gq, dim3(256), 0, st, p);            \
+  } while (0)
+  if (p.hd > 16) { if (p.thresh) DM_BWD(2, true); else DM_BWD(2, false); }
+  else { if (p.thresh) DM_BWD(1, true); else DM_BWD(1, false); }
+#undef DM_BWD
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
