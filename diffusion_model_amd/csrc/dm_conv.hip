@@ -269,6 +269,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   __syncthreads();
 
   int s = 0, cc = 0;
+#if defined(DM_ABLATE)
+  bf16x8 abl_a[MT], abl_b[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abl_a[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) abl_b[nt] = *reinterpret_cast<const bf16x8*>(sB + nt * 1024 + lane * 16);
+#endif
   auto step = [&](int g, u32x4(&br_free)[B_PER_THREAD], u32x4(&br_next)[B_PER_THREAD]) {
     // br_free: register set of stage g (already in LDS) -> refill with stage g + 2
     // br_next: holds stage g + 1 -> goes to LDS at the end of this step
@@ -286,12 +293,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       const int kw = (TAPS == 9) ? tap - 3 * kh : 0;
       const int tapoff = (kh * PITCH + kw) * STRIDE + ks * 64;
       bf16x8 av[MT], bv[NT];
+#if defined(DM_ABLATE) && (DM_ABLATE & 16)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt] = abl_a[mt];
+#else
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
+#endif
+#if defined(DM_ABLATE) && (DM_ABLATE & 8)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bv[nt] = abl_b[nt];
+#else
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
+#endif
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -308,6 +325,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       s = 0; ++cc;
     }
     if (g + 1 < G) store_b((g + 1) & 1, br_next);
+#if defined(DM_ABLATE) && (DM_ABLATE & 4)
+    if (p.B < 0)
+#endif
     __syncthreads();
   };
   for (int g = 0; g < G; g += 2) {

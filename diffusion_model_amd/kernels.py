@@ -5,6 +5,7 @@ contiguous; slices along the channel dim are allowed (pixel stride = stride(-2))
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -47,8 +48,9 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """A per-device scratch buffer that only ever grows (stable under graph replay once warm)."""
-    key = torch.device(device).index or 0
+    """A per-(device, stream) scratch buffer that only ever grows (stable under graph replay once warm).
+    Kernels on different streams must not share scratch: the weight-gradient side stream gets its own."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -146,6 +148,45 @@ def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0
     a.taps, a.mode, a.act_silu_in, a.n_valid, a.k_valid = taps, mode, int(act_silu_in), n_valid, k_valid
     a.workspace, a.ws_bytes = _p(ws), ws.numel()
     check(L.dm_wgrad(C.byref(a), _stream()), "dm_wgrad")
+
+
+# Weight gradients are off the backward critical path (nothing downstream in the same backward reads
+# them), so the UNet enqueues them on a side HIP stream: they fill the CUs that the data-gradient chain
+# (dgrad convs, GroupNorm / attention backward: HBM- or VALU-bound) leaves idle.  join_side() makes the
+# current stream wait for them; it is called before gradients are consumed (bucket all-reduce, optimizer,
+# autograd hand-back).
+SIDE_WGRAD = os.environ.get("DM_SIDE_WGRAD", "1") != "0"
+_SIDE = {}
+_SIDE_DIRTY = set()
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index or 0
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
+
+
+def wgrad_side(x, dy, dw, dbias=None, **kw):
+    if not SIDE_WGRAD:
+        return wgrad(x, dy, dw, dbias, **kw)
+    dev = x.device
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        wgrad(x, dy, dw, dbias, **kw)
+    x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
+    dy.record_stream(side)
+    _SIDE_DIRTY.add(dev.index or 0)
+
+
+def join_side(device=None) -> None:
+    key = torch.device(device).index or 0 if device is not None else torch.cuda.current_device()
+    if key in _SIDE_DIRTY:
+        torch.cuda.current_stream(key).wait_stream(_SIDE[key])
+        _SIDE_DIRTY.discard(key)
 
 
 # --------------------------------------------------------------------------- norm

@@ -119,6 +119,7 @@ class _Fn(torch.autograd.Function):
     def backward(ctx, dout):
         g = Grads()
         dins = ctx.mod._run_bwd(dout.contiguous(), ctx.saved, g, ctx.need_in)
+        K.join_side(dout.device)  # weight gradients were enqueued on the side stream
         dins = list(dins) + [None] * (ctx.n_in - len(dins))
         pg = []
         for p in ctx.params:
@@ -202,12 +203,12 @@ class ResBlock(HipModule):
         B = x.shape[0]
         lin = self.time_mlp[1]
         d_g2 = K.conv3x3(dy, PW.of(self.conv2).bwd, self.cout)
-        K.wgrad(g2, dy, g.of(self.conv2.weight), g.of(self.conv2.bias))
+        K.wgrad_side(g2, dy, g.of(self.conv2.weight), g.of(self.conv2.bias))
         if isinstance(self.skip, nn.Identity):
             dsk = dy
         else:
             dsk = K.gemm(dy, PW.of(self.skip).bwd, self.cin)
-            K.wgrad(x, dy, g.of(self.skip.weight), g.of(self.skip.bias), taps=1)
+            K.wgrad_side(x, dy, g.of(self.skip.weight), g.of(self.skip.bias), taps=1)
         dh = K.gn_silu_bwd(h, d_g2, self.norm2.weight.detach(), self.norm2.bias.detach(), st2, self.groups,
                            g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed)
         dtp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
@@ -215,14 +216,14 @@ class ResBlock(HipModule):
         K.batchsum(dtp, g.of(self.conv1.bias))
         K.batchsum(dtp, g.of(lin.bias))
         dtp16 = K.to_bf16(dtp)
-        K.wgrad(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
+        K.wgrad_side(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
         d_this = torch.empty((B, temb.shape[-1]), dtype=torch.float32, device=x.device)
         K.gemm(dtp16, PW.of(lin).bwd, temb.shape[-1], out_f32=d_this)
         if dts is None:
             dts = d_this
         else:  # fp32 accumulation across the ResBlocks (batchsum with one "batch" row == axpy)
             K.batchsum(d_this.view(1, -1), dts.view(-1))
-        K.wgrad(g1, dh, g.of(self.conv1.weight), None)
+        K.wgrad_side(g1, dh, g.of(self.conv1.weight), None)
         dx = None
         if need_dx:
             d_g1 = K.conv3x3(dh, PW.of(self.conv1).bwd, self.cin)
@@ -278,12 +279,12 @@ class Attention(HipModule):
         B, N, C = tok.shape
         dyt = dy.view(B, N, C)
         d_o = K.gemm(dyt, PW.of(self.linear_out).bwd, C)
-        K.wgrad(o, dyt, g.of(self.linear_out.weight), None, taps=1)
+        K.wgrad_side(o, dyt, g.of(self.linear_out.weight), None, taps=1)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         K.attn_bwd(q, k, v, o, lse, d_o, self.num_heads, dq=dqkv[..., :C], dk=dqkv[..., C:2 * C],
                    dv=dqkv[..., 2 * C:], drop_p=p, drop_seed=seed)
-        K.wgrad(tok, dqkv, g.of(self.linear_qkv.weight), None, taps=1)
+        K.wgrad_side(tok, dqkv, g.of(self.linear_qkv.weight), None, taps=1)
         dx = K.gemm(dqkv, PW.of(self.linear_qkv).bwd, C, res=None if add is None else add.view(B, N, C))
         return dx.view(dy.shape)
 
@@ -332,11 +333,11 @@ class CrossAttention(HipModule):
         B, N, C = tok.shape
         dyt = dy.view(B, N, C)
         d_o = K.gemm(dyt, PW.of(self.to_out).bwd, C)
-        K.wgrad(o, dyt, g.of(self.to_out.weight), None, taps=1)
+        K.wgrad_side(o, dyt, g.of(self.to_out.weight), None, taps=1)
         dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
-        K.wgrad(tok, dq, g.of(self.to_q.weight), None, taps=1)
-        K.wgrad(ctx, dk, g.of(self.to_k.weight), None, taps=1)
-        K.wgrad(ctx, dv, g.of(self.to_v.weight), None, taps=1)
+        K.wgrad_side(tok, dq, g.of(self.to_q.weight), None, taps=1)
+        K.wgrad_side(ctx, dk, g.of(self.to_k.weight), None, taps=1)
+        K.wgrad_side(ctx, dv, g.of(self.to_v.weight), None, taps=1)
         dx = K.gemm(dq, PW.of(self.to_q).bwd, C, res=None if add is None else add.view(B, N, C))
         dctx = None
         if need_dctx:
@@ -376,7 +377,7 @@ class Upsample(HipModule):
 
     def _bwd(self, dy, saved, g: Grads, add=None):
         (x,) = saved
-        K.wgrad(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=2)
+        K.wgrad_side(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=2)
         dx = K.conv3x3(dy, PW.of(self.conv).bwd, self.ch, pool2=True)
         return dx if add is None else K.add(dx, add)
 
@@ -404,7 +405,7 @@ class Downsample(HipModule):
 
     def _bwd(self, dy, saved, g: Grads, add=None):
         (x,) = saved
-        K.wgrad(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=1)
+        K.wgrad_side(x, dy, g.of(self.conv.weight), g.of(self.conv.bias), mode=1)
         return K.conv3x3(dy, PW.of(self.conv).bwd, self.ch, mode=3, res=add)
 
     def forward(self, x):
@@ -473,7 +474,7 @@ class UnetLayer(HipModule):
             B, H2, W2, Ch = dy.shape
             dyt = dy.view(B, H2 * W2, Ch)
             du = K.gemm(dyt, PW.of(self.conv).bwd, 2 * Ch)
-            K.wgrad(u.view(B, H2 * W2, 2 * Ch), dyt, g.of(self.conv.weight), g.of(self.conv.bias), taps=1)
+            K.wgrad_side(u.view(B, H2 * W2, 2 * Ch), dyt, g.of(self.conv.weight), g.of(self.conv.bias), taps=1)
             dxo = self.upsample._bwd(du.view(B, H2, W2, 2 * Ch), s_ud, g)
         else:
             dxo = self.downsample._bwd(dy, s_ud, g, add=d_skip)
@@ -587,16 +588,23 @@ class UNET(HipModule):
         dy16 = K.nchw_to_nhwc(dout.detach().float().contiguous(), 16 if self.cout_img <= 16 else 0)
         kp = dy16.shape[-1]
         oc = self.output_conv
-        K.wgrad(a2.view(B, M, Ch), dy16.view(B, M, kp), g.of(oc.weight).view(self.cout_img, Ch), g.of(oc.bias), taps=1,
+        K.wgrad_side(a2.view(B, M, Ch), dy16.view(B, M, kp), g.of(oc.weight).view(self.cout_img, Ch), g.of(oc.bias), taps=1,
                 act_silu_in=True, n_valid=self.cout_img)
         d_s2 = K.gemm(dy16.view(B, M, kp), PW.of(oc).bwd, Ch)
         d_a2 = K.silu_bwd(d_s2.view(B, Hc, Wc, Ch), a2)
-        K.wgrad(a1, d_a2, g.of(self.late_conv2.weight), g.of(self.late_conv2.bias), act_silu_in=True)
+        K.wgrad_side(a1, d_a2, g.of(self.late_conv2.weight), g.of(self.late_conv2.bias), act_silu_in=True)
         d_s1 = K.conv3x3(d_a2, PW.of(self.late_conv2).bwd, Ch)
         d_a1 = K.silu_bwd(d_s1, a1)
-        K.wgrad(cat, d_a1, g.of(self.late_conv1.weight), g.of(self.late_conv1.bias))
+        K.wgrad_side(cat, d_a1, g.of(self.late_conv1.weight), g.of(self.late_conv1.bias))
         d_cat = K.conv3x3(d_a1, PW.of(self.late_conv1).bwd, Cc)
-        hook = self.__dict__.get("_bwd_hook") or (lambda stage: None)
+        user_hook = self.__dict__.get("_bwd_hook")
+
+        def hook(stage):  # gradients of a finished stage are about to be consumed: join the wgrad stream
+            if user_hook is not None:
+                K.join_side(da_dev)
+                user_hook(stage)
+
+        da_dev = dout.device
         hook("head")
         dts = None
         d_skips: List[Optional[torch.Tensor]] = [None] * L
@@ -612,7 +620,7 @@ class UNET(HipModule):
             hook(f"Layer{i + 1}")
         # input conv
         ic = self.input_conv
-        K.wgrad(x0, da, g.of(ic.weight), g.of(ic.bias), k_valid=self.cin)
+        K.wgrad_side(x0, da, g.of(ic.weight), g.of(ic.bias), k_valid=self.cin)
         dx = None
         if need_dx:
             # rare path (callers normally do not differentiate wrt the image): the data-gradient
@@ -624,11 +632,12 @@ class UNET(HipModule):
         # time MLP
         l0, l2 = self.time_mlp[0], self.time_mlp[2]
         dtemb = K.silu_bwd(K.to_bf16(dts), temb)
-        K.wgrad(h1, dtemb, g.of(l2.weight), g.of(l2.bias), taps=1, act_silu_in=True)
+        K.wgrad_side(h1, dtemb, g.of(l2.weight), g.of(l2.bias), taps=1, act_silu_in=True)
         dsh1 = K.gemm(dtemb, PW.of(l2).bwd, self.temb_dim)
         dh1 = K.silu_bwd(dsh1, h1)
-        K.wgrad(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
+        K.wgrad_side(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
         hook("tail")
+        K.join_side(da_dev)
         return dx
 
     # ------------------------------------------------------------------ public API

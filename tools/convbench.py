@@ -80,3 +80,34 @@ for name, mode, H, cin, cout in LAYERS:
         fl = 2.0 * B * Ho * Ho * cout * cin * 9
         by = 2.0 * B * (H * H * cin + Ho * Ho * cout)
     print(f"{name:36s} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s", flush=True)
+
+# ---- weight gradients (dW += dy^T * patches(x)), same layer shapes
+WG = [("wgrad L1.conv 64->64@96", 0, 96, 64, 64), ("wgrad L2.conv2 128->128@48", 0, 48, 128, 128),
+      ("wgrad L3.conv2 256->256@24", 0, 24, 256, 256), ("wgrad L3.up 256->256 24->48", 2, 24, 256, 256),
+      ("wgrad L4.conv1 256->128@48", 0, 48, 256, 128), ("wgrad L4.up 128->128 48->96", 2, 48, 128, 128),
+      ("wgrad late1 128->64@96", 0, 96, 128, 64), ("wgrad L1.down s2 64->64", 1, 96, 64, 64),
+      ("wgrad gemm L2.qkv 128->384 M=147k", "g", 147456, 128, 384),
+      ("wgrad gemm L4.conv1x1 128->64 M=590k", "g", 589824, 128, 64),
+      ("wgrad gemm L1.to_q 64->64 M=590k", "g", 589824, 64, 64)]
+for name, mode, H, cin, cout in WG:
+    if args.only and args.only not in name:
+        continue
+    if mode == "g":
+        M = H * B // 64
+        x = torch.randn(M, cin, device=dev).to(torch.bfloat16)
+        dy = torch.randn(M, cout, device=dev).to(torch.bfloat16)
+        dw = torch.zeros(cout, cin, device=dev)
+        db = torch.zeros(cout, device=dev)
+        t = timeit(lambda: K.wgrad(x, dy, dw, db, taps=1), args.reps)
+        fl = 2.0 * M * cin * cout
+        by = 2.0 * M * (cin + cout)
+    else:
+        x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
+        Ho = H // 2 if mode == 1 else (2 * H if mode == 2 else H)
+        dy = torch.randn(B, Ho, Ho, cout, device=dev).to(torch.bfloat16)
+        dw = torch.zeros(cout, cin, 3, 3, device=dev)
+        db = torch.zeros(cout, device=dev)
+        t = timeit(lambda: K.wgrad(x, dy, dw, db, taps=9, mode=mode), args.reps)
+        fl = 2.0 * B * Ho * Ho * cout * cin * 9
+        by = 2.0 * B * (H * H * cin + Ho * Ho * cout)
+    print(f"{name:36s} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s", flush=True)
