@@ -52,6 +52,68 @@ template <int MT, int NT, int TW, int MODE>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MT][NT], int nb, int wave, int lane,
                                               int b, int h0, int w0, long m0) {
   const int cq = (lane >> 4) * 4;
+  // ---- wide path: bf16 output, whole channel tiles.  A lane holds 4 couts of tile nt and 4 of tile nt+1 (two
+  // 8-byte stores); one v_permlane16_swap per dword trades halves with the lane 16 away, after which every lane
+  // owns 8 CONSECUTIVE couts -> one 16-byte store (half the store instructions, 64-byte row segments).
+  if constexpr (NT % 2 == 0) {
+    if (p.y && !p.yf && !p.pool2 && p.n_valid == p.Cout && (p.ldy & 7) == 0 &&
+        (reinterpret_cast<unsigned long long>(p.y) & 15) == 0) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int q = (wave * MT + mt) * 16 + (lane & 15);
+        long pix;
+        int bb = b;
+        bool ok;
+        if constexpr (MODE == MODE_GEMM) {
+          pix = m0 + q;
+          ok = pix < p.M;
+          bb = ok ? (int)(pix / p.rows_per_batch) : 0;
+        } else {
+          const int r = q / TW, c = q % TW;
+          ok = (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile may overhang the image
+          pix = ((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c);
+        }
+        if (!ok) pix = 0;
+        uint32_t rs = 0u;
+        if (p.drop_thresh) rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) {
+          u32x2 pk[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int co = (nb * NT + nt + h) * 16 + cq;
+            f32x4 v = acc[mt][nt + h];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+            if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
+            if (p.drop_thresh) {
+              const uint32_t b0 = dm_drop_bits(rs, (uint32_t)co >> 1), b1 = dm_drop_bits(rs, ((uint32_t)co >> 1) + 1);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                v[j] = dm_keep16(j < 2 ? b0 : b1, (uint32_t)j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+            }
+            if (p.res) {
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+            pk[h] = __builtin_bit_cast(u32x2, o);
+          }
+          // odd 16-lane rows of pk[0] <-> even rows of pk[1]
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          if (ok) {
+            const int co8 = (nb * NT + nt + (g & 1)) * 16 + 4 * (g & ~1);
+            *reinterpret_cast<u32x4*>(p.y + pix * p.ldy + co8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co = (nb * NT + nt) * 16 + cq;
@@ -269,21 +331,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   __syncthreads();
 
   int s = 0, cc = 0;
-#if defined(DM_ABLATE)
-  bf16x8 abl_a[MT], abl_b[NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abl_a[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt]);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) abl_b[nt] = *reinterpret_cast<const bf16x8*>(sB + nt * 1024 + lane * 16);
-#endif
   auto step = [&](int g, u32x4(&br_free)[B_PER_THREAD], u32x4(&br_next)[B_PER_THREAD]) {
     // br_free: register set of stage g (already in LDS) -> refill with stage g + 2
     // br_next: holds stage g + 1 -> goes to LDS at the end of this step
-#if defined(DM_ABLATE) && (DM_ABLATE & 2)
-    if (g + 2 < G && p.B < 0) load_b(g + 2, br_free);
-#else
     if (g + 2 < G) load_b(g + 2, br_free);
-#endif
     const char* sBc = sB + (g & 1) * B_STAGE;
 #pragma unroll
     for (int ksl = 0; ksl < KSPS; ++ksl) {
@@ -293,22 +344,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       const int kw = (TAPS == 9) ? tap - 3 * kh : 0;
       const int tapoff = (kh * PITCH + kw) * STRIDE + ks * 64;
       bf16x8 av[MT], bv[NT];
-#if defined(DM_ABLATE) && (DM_ABLATE & 16)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt] = abl_a[mt];
-#else
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
-#endif
-#if defined(DM_ABLATE) && (DM_ABLATE & 8)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bv[nt] = abl_b[nt];
-#else
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
-#endif
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -325,9 +366,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       s = 0; ++cc;
     }
     if (g + 1 < G) store_b((g + 1) & 1, br_next);
-#if defined(DM_ABLATE) && (DM_ABLATE & 4)
-    if (p.B < 0)
-#endif
     __syncthreads();
   };
   for (int g = 0; g < G; g += 2) {
