@@ -59,6 +59,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
     if (p.y && !p.yf && !p.pool2 && p.n_valid == p.Cout && (p.ldy & 7) == 0 &&
         (reinterpret_cast<unsigned long long>(p.y) & 15) == 0) {
       const int g = lane >> 4;
+      const bool wide_res = p.res && (p.ldr & 7) == 0 && (reinterpret_cast<unsigned long long>(p.res) & 15) == 0;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int q = (wave * MT + mt) * 16 + (lane & 15);
@@ -80,6 +81,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int nt = 0; nt < NT; nt += 2) {
           u32x2 pk[2];
+          const int co8 = (nb * NT + nt + (g & 1)) * 16 + 4 * (g & ~1);  // this lane's 8 consecutive couts
+          u32x2 rres[2] = {{0u, 0u}, {0u, 0u}};
+          if (p.res) {
+            // the residual comes in the same 16-byte shape and is dealt back to the MFMA layout by the same swap
+            u32x4 rv = {0u, 0u, 0u, 0u};
+            if (wide_res && ok) rv = *reinterpret_cast<const u32x4*>(p.res + pix * p.ldr + co8);
+            const auto r0 = __builtin_amdgcn_permlane16_swap(rv[0], rv[2], false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(rv[1], rv[3], false, false);
+            rres[0] = u32x2{r0[0], r1[0]};
+            rres[1] = u32x2{r0[1], r1[1]};
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int co = (nb * NT + nt + h) * 16 + cq;
@@ -93,7 +105,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
                 v[j] = dm_keep16(j < 2 ? b0 : b1, (uint32_t)j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
             }
             if (p.res) {
-              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
+              bf16x4 rv = __builtin_bit_cast(bf16x4, rres[h]);
+              if (!wide_res) rv = *reinterpret_cast<const bf16x4*>(p.res + pix * p.ldr + co);
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
             }
@@ -106,7 +119,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
           if (ok) {
-            const int co8 = (nb * NT + nt + (g & 1)) * 16 + 4 * (g & ~1);
             *reinterpret_cast<u32x4*>(p.y + pix * p.ldy + co8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
           }
         }
@@ -515,13 +527,15 @@ template <int NT>
 int dispatch_gemm_stream(const ConvParams& p, hipStream_t st) {
   const int nks = ((p.Cin + 63) / 64) * 2;
   const bool big = p.M >= 262144;  // enough rows for 32-row wave tiles to balance over the CUs
+  // 32-row wave tiles only where both X tiles in flight plus the accumulators fit the register file
   if (nks <= 2) return big ? launch_gemm_stream<2, NT, 2>(p, st) : launch_gemm_stream<1, NT, 2>(p, st);
-  if (nks <= 4) return big ? launch_gemm_stream<2, NT, 4>(p, st) : launch_gemm_stream<1, NT, 4>(p, st);
+  if (nks <= 4) {
+    if constexpr (NT <= 4) { if (big) return launch_gemm_stream<2, NT, 4>(p, st); }
+    return launch_gemm_stream<1, NT, 4>(p, st);
+  }
+  if (nks <= 8) return launch_gemm_stream<1, NT, 8>(p, st);
   if constexpr (NT <= 4) {
-    if (nks <= 8) return big ? launch_gemm_stream<2, NT, 8>(p, st) : launch_gemm_stream<1, NT, 8>(p, st);
     if (nks <= 16) return launch_gemm_stream<1, NT, 16>(p, st);
-  } else {
-    if (nks <= 8) return launch_gemm_stream<1, NT, 8>(p, st);
   }
   return 1;  // not handled here
 }
