@@ -75,9 +75,9 @@ __device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
 }
 
 // ---------------------------------------------------------------- forward
-// DROP and the edge (partial last key block) handling are compile-time: the compiler if-converts runtime
+// DROP and EDGE (Nk not a multiple of 64: key-range masks, applied in every block of that rarer variant) are compile-time: the compiler if-converts runtime
 // `if (p.thresh)` / `if (edge)` guards into unconditional hash + select code, which the eval path then pays for.
-template <int DT, bool DROP>
+template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   store_piece(sKb[0], tid, rk0);
   store_piece(sVb[0], tid, rv0);
   __syncthreads();
-  auto block = [&](auto edge_c, int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    constexpr bool EDGE = decltype(edge_c)::value;
+  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
     if (kb + 2 < nkb) {
       rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
       rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
@@ -193,14 +192,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
     __syncthreads();
   };
-  const bool has_edge = (p.Nk & 63) != 0;
-  auto run = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    if (has_edge && kb == nkb - 1) block(std::true_type{}, kb, rk_free, rv_free, rk_next, rv_next);
-    else block(std::false_type{}, kb, rk_free, rv_free, rk_next, rv_next);
-  };
   for (int kb = 0; kb < nkb; kb += 2) {
-    run(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) run(kb + 1, rk1, rv1, rk0, rv0);
+    block(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -375,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
 }
 
 // dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
-template <int DT, bool DROP>
+template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
@@ -413,8 +407,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
   store_piece(sVb[0], tid, rv0);
   __syncthreads();
   const float ik = DROP ? p.inv_keep : 1.f;
-  auto block = [&](auto edge_c, int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    constexpr bool EDGE = decltype(edge_c)::value;
+  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
     if (kb + 2 < nkb) {
       rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
       rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
@@ -468,14 +461,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
     }
     __syncthreads();
   };
-  const bool has_edge = (p.Nk & 63) != 0;
-  auto run = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    if (has_edge && kb == nkb - 1) block(std::true_type{}, kb, rk_free, rv_free, rk_next, rv_next);
-    else block(std::false_type{}, kb, rk_free, rv_free, rk_next, rv_next);
-  };
   for (int kb = 0; kb < nkb; kb += 2) {
-    run(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) run(kb + 1, rk1, rv1, rk0, rv0);
+    block(kb, rk0, rv0, rk1, rv1);
+    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -716,13 +704,13 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     return DM_OK;
   }
   const dim3 grid((p.Nq + 127) / 128, p.B * p.H);
-  if (p.thresh) {
-    if (p.hd > 16) hipLaunchKernelGGL((attn_fwd_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  } else {
-    if (p.hd > 16) hipLaunchKernelGGL((attn_fwd_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  }
+  const bool edge = (p.Nk & 63) != 0;
+#define DM_FWD(DT, DROP, EDGE) hipLaunchKernelGGL((attn_fwd_kernel<DT, DROP, EDGE>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define DM_FWD2(DT, DROP) do { if (edge) DM_FWD(DT, DROP, true); else DM_FWD(DT, DROP, false); } while (0)
+  if (p.hd > 16) { if (p.thresh) DM_FWD2(2, true); else DM_FWD2(2, false); }
+  else { if (p.thresh) DM_FWD2(1, true); else DM_FWD2(1, false); }
+#undef DM_FWD2
+#undef DM_FWD
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
@@ -753,11 +741,13 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
   DM_LAUNCH_CHECK();
   const dim3 gkv((p.Nk + 63) / 64, p.B * p.H), gq((p.Nq + 127) / 128, p.B * p.H);
+  const bool edge = (p.Nk & 63) != 0;
 #define DM_BWD(DT, DROP)                                                                   \
   do {                                                                                     \
     hipLaunchKernelGGL((attn_bwd_kv_kernel<DT, DROP>), gkv, dim3(256), 0, st, p);          \
     DM_LAUNCH_CHECK();                                                                     \
-    hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP>), gq, dim3(256), 0, st, p);            \
+    if (edge) hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP, true>), gq, dim3(256), 0, st, p);  \
+    else hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP, false>), gq, dim3(256), 0, st, p);      \
   } while (0)
   if (p.hd > 16) { if (p.thresh) DM_BWD(2, true); else DM_BWD(2, false); }
   else { if (p.thresh) DM_BWD(1, true); else DM_BWD(1, false); }

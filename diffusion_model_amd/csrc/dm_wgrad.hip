@@ -328,6 +328,7 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
     else pl.tw = 8;
     pl.ntiles = B * up(Ho, pl.th) * up(Wo, pl.tw);
   }
+  // 512 workgroups (two per CU) in total: measured best against 384 / 256 on every conv layer but one
   int ns = 512 / (pl.ncot * pl.ncit);
   if (ns < 1) ns = 1;
   if (ns > pl.ntiles) ns = pl.ntiles;
