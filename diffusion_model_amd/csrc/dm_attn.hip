@@ -81,6 +81,7 @@ template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];  // dropout column words of the staged key block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   }
   store_piece(sKb[0], tid, rk0);
   store_piece(sVb[0], tid, rv0);
+  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid);
   __syncthreads();
   auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
     if (kb + 2 < nkb) {
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
       for (int kt = 0; kt < 4; ++kt) {
         uint32_t db0 = 0u, db1 = 0u;
         if constexpr (DROP) {
-          const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
-          db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
+          const u32x2 cw = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + kt * 8 + 2 * g);
+          db0 = rs ^ cw[0]; db1 = rs ^ cw[1];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     if (kb + 1 < nkb) {
       store_piece(sKb[(kb + 1) & 1], tid, rk_next);
       store_piece(sVb[(kb + 1) & 1], tid, rv_next);
+      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid));
     }
     __syncthreads();
   };
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
   for (int dt = 0; dt < DT; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Nq + 63) / 64;
+  const uint32_t cw = DROP ? dm_attn_colword(p.seed, (uint32_t)key >> 1) : 0u;  // this lane's key pair
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
   struct Regs { u32x4 q, o; float l, d; uint32_t rs; };
   auto fetch = [&](int qb, Regs& r) {
@@ -290,23 +294,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     const float* sD = sDb[qb & 1];
     f32x4 pt[4], ds[4];
     const float ikl = DROP ? p.inv_keep : 1.f;
-    // Dropout bits: a lane holds ONE key and 16 queries per block, its neighbour (li ^ 1) the other key
-    // of the same 16-bit pair -> each of the two hashes half of the (query, pair) words and they swap
-    // through DPP.  Row states come precomputed per query from LDS.
-    uint32_t hb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, ho[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    const bool odd = (li & 1) != 0;
-    if constexpr (DROP) {
-      const uint32_t pk = dm_drop_pairkey((uint32_t)key >> 1);
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const u32x4 r4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + ((odd ? 2 : 0) + a) * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          hb[a][r] = dm_drop_mix(r4[r] + pk);
-          ho[a][r] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb[a][r], 0xB1, 0xF, 0xF, false);  // lane ^ 1
-        }
-      }
-    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + g * 16);
@@ -315,6 +302,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
       const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const f32x4 L4 = *reinterpret_cast<const f32x4*>(sL + qt * 16 + 4 * g);
       const f32x4 D4 = *reinterpret_cast<const f32x4*>(sD + qt * 16 + 4 * g);
+      u32x4 R4 = {0u, 0u, 0u, 0u};  // per-query dropout row words
+      if constexpr (DROP) R4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + qt * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // no per-element masks: invalid queries carry L = +1e30 (p = 0); invalid keys only pollute their
@@ -322,8 +311,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
         float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L4[r]));
         float pd = pv, dpv = dp[r];
         if constexpr (DROP) {
-          const bool mine = ((qt >> 1) != 0) == odd;
-          const bool keep = dm_keep16(mine ? hb[qt & 1][r] : ho[qt & 1][r], (uint32_t)key, p.thresh);
+          const bool keep = dm_keep16(R4[r] ^ cw, (uint32_t)key, p.thresh);
           pd = keep ? pv : 0.f;
           dpv = keep ? dpv : 0.f;
         }
@@ -373,6 +361,7 @@ template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -405,7 +394,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
   }
   store_piece(sKb[0], tid, rk0);
   store_piece(sVb[0], tid, rv0);
+  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid);
   __syncthreads();
+  uint32_t rsq[2] = {0u, 0u};
+  if constexpr (DROP) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) rsq[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
+  }
   const float ik = DROP ? p.inv_keep : 1.f;
   auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
     if (kb + 2 < nkb) {
@@ -425,9 +420,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
         const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         uint32_t db0 = 0u, db1 = 0u;
         if constexpr (DROP) {
-          const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
-          const uint32_t pair = (uint32_t)(kb * 64 + kt * 16 + 4 * g) >> 1;
-          db0 = dm_drop_bits(rs, pair); db1 = dm_drop_bits(rs, pair + 1);
+          const u32x2 cw = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + kt * 8 + 2 * g);
+          db0 = rsq[qt] ^ cw[0]; db1 = rsq[qt] ^ cw[1];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -458,6 +452,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
     if (kb + 1 < nkb) {
       store_piece(sKb[(kb + 1) & 1], tid, rk_next);
       store_piece(sVb[(kb + 1) & 1], tid, rv_next);
+      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid));
     }
     __syncthreads();
   };

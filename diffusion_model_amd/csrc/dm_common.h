@@ -71,6 +71,14 @@ __device__ __forceinline__ uint32_t dm_drop_pairkey(uint32_t pair) { return pair
 __device__ __forceinline__ uint32_t dm_drop_bits(uint32_t rowstate, uint32_t pair) {
   return dm_drop_mix(rowstate + dm_drop_pairkey(pair));
 }
+// Attention-probability dropout draws its 32-bit word for (row, column pair) as rowword ^ colword: the row
+// word is dm_drop_row(seed, row), the column word below depends on (seed, pair) only.  Marginals are uniform
+// and any two cells are independent (pairwise independence); what is given up against a full hash per cell is
+// higher-order independence (the four words on a rectangle of the row x pair grid XOR to zero), in exchange
+// for ONE v_xor per two score elements inside the VALU-bound attention loops.
+__device__ __forceinline__ uint32_t dm_attn_colword(uint32_t seed, uint32_t pair) {
+  return dm_drop_mix((seed ^ 0x85EBCA6Bu) + dm_drop_pairkey(pair));
+}
 __device__ __forceinline__ bool dm_keep16(uint32_t bits32, uint32_t col, uint32_t thresh16) {
   // 16-bit field (col & 1) of bits32 >= thresh16, compared in the high half (no field extraction)
   return ((col & 1u) ? bits32 : (bits32 << 16)) >= (thresh16 << 16);
