@@ -68,7 +68,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p]),
     "dm_gn_silu_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
-                               c_int, c_int, c_float, c_ulonglong, c_void_p, c_long, c_void_p]),
+                               c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_attn_bwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     long lddy, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
     const float* __restrict__ ws, int nsplit, float* __restrict__ sums, const bf16* __restrict__ add_in, long ldadd,
     bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
-    uint32_t drop_thresh, float drop_scale) {
+    uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum) {
   __shared__ float s_s1[256], s_s2[256], s_m1[64], s_m2[64];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   }
   const int per = (HW + nchunk - 1) / nchunk;
   const int p_begin = chunk * per, p_end = min(HW, p_begin + per);
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // per-(sample, channel) sums of dx (optional output)
   for (int pix = p_begin + prow; pix < p_end; pix += ppi) {
     const long gp = (long)b * HW + pix;
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + gp * ldx + c0);
@@ -242,8 +243,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
       if (drop_thresh) r = dm_keep16(db[j >> 1], (uint32_t)j, drop_thresh) ? r * drop_scale : 0.f;
       if (add_in) r += (float)a8[j];
       o[j] = (bf16)r;
+      csum[j] += (float)o[j];
     }
     *reinterpret_cast<bf16x8*>(dx + gp * lddx + c0) = o;
+  }
+  if (dx_colsum) {
+    // column sums of the written dx: LDS atomics across the block's pixel rows, then one global atomic per
+    // (chunk, channel) -- replaces a separate pass over dx (the time-embedding / bias gradient of the ResBlock)
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) s_s1[c] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&s_s1[c0 + j], csum[j]);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) unsafeAtomicAdd(dx_colsum + (long)b * C + c, s_s1[c]);
   }
 }
 
@@ -297,8 +310,8 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
 extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
                               const float* gamma, const float* beta, const float* stats, const void* add_in,
                               long ldadd, void* dx, long lddx, float* dgamma, float* dbeta, int B, int HW, int C,
-                              int G, int act_silu, float drop_p, unsigned long long drop_seed, void* workspace,
-                              long ws_bytes, dm_stream_t stream) {
+                              int G, int act_silu, float drop_p, unsigned long long drop_seed, float* dx_colsum,
+                              void* workspace, long ws_bytes, dm_stream_t stream) {
   DM_REQUIRE(x && dy && dx && gamma && beta && stats && workspace && dgamma && dbeta);
   DM_REQUIRE(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0 && C <= 256);
   DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!add_in || ldadd % 8 == 0));
@@ -314,7 +327,7 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, ws, ns, sums, (const bf16*)add_in, ldadd, (bf16*)dx,
-                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale);
+                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum);
   DM_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dgamma, dbeta, B, C);
   DM_LAUNCH_CHECK();

@@ -207,7 +207,8 @@ def gn_silu_fwd(x, gamma, beta, groups, *, chan_add=None, eps=1e-5, act=True, ou
 
 
 def gn_silu_bwd(x, dy, gamma, beta, stats, groups, dgamma, dbeta, *, chan_add=None, add_in=None, act=True,
-                drop_p=0.0, drop_seed=0, out=None):
+                drop_p=0.0, drop_seed=0, out=None, colsum_out=None):
+    """colsum_out: optional fp32 [B, C], += per-sample channel sums of the returned dx (same pass)."""
     ldx, lddy = _act(x, "x"), _act(dy, "dy")
     Cc = x.shape[-1]
     B = x.shape[0]
@@ -219,7 +220,8 @@ def gn_silu_bwd(x, dy, gamma, beta, stats, groups, dgamma, dbeta, *, chan_add=No
     check(L.dm_gn_silu_bwd(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(dy), lddy, _p(gamma), _p(beta),
                            _p(_f32(stats, "stats")), _p(add_in), 0 if add_in is None else _act(add_in, "add_in"),
                            _p(out), _act(out, "out"), _p(_f32(dgamma, "dgamma")), _p(_f32(dbeta, "dbeta")),
-                           B, HW, Cc, groups, int(act), float(drop_p), int(drop_seed), _p(ws), ws.numel(),
+                           B, HW, Cc, groups, int(act), float(drop_p), int(drop_seed), _p(_f32(colsum_out, "colsum_out")),
+                           _p(ws), ws.numel(),
                            _stream()), "dm_gn_silu_bwd")
     return out
 

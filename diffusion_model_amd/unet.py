@@ -209,10 +209,9 @@ class ResBlock(HipModule):
         else:
             dsk = K.gemm(dy, PW.of(self.skip).bwd, self.cin)
             K.wgrad_side(x, dy, g.of(self.skip.weight), g.of(self.skip.bias), taps=1)
+        dtp = torch.zeros((B, self.cout), dtype=torch.float32, device=x.device)
         dh = K.gn_silu_bwd(h, d_g2, self.norm2.weight.detach(), self.norm2.bias.detach(), st2, self.groups,
-                           g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed)
-        dtp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
-        K.colsum(dh, dtp, B)
+                           g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed, colsum_out=dtp)
         K.batchsum(dtp, g.of(self.conv1.bias))
         K.batchsum(dtp, g.of(lin.bias))
         dtp16 = K.to_bf16(dtp)

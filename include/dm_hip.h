@@ -113,11 +113,13 @@ int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, const float* 
                    void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
                    void* workspace, long ws_bytes, dm_stream_t stream);
 /* dx = d/dx of the above (+ add_in), optional dropout mask (the mask dm_conv3x3 applied to x);
- * dgamma/dbeta accumulated (+=). */
+ * dgamma/dbeta accumulated (+=).  dx_colsum (optional, [B][C] fp32, accumulated +=): per-sample channel sums
+ * of the written dx = the gradient of the time-embedding projection / conv1 bias of the ResBlock
+ * (unet.py:101-102), produced in the same pass instead of a separate reduction over dx. */
 int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
                    const float* gamma, const float* beta, const float* stats, const void* add_in, long ldadd,
                    void* dx, long lddx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int act_silu,
-                   float drop_p, unsigned long long drop_seed, void* workspace, long ws_bytes,
+                   float drop_p, unsigned long long drop_seed, float* dx_colsum, void* workspace, long ws_bytes,
                    dm_stream_t stream);
 
 /* ------------------------------------------------------------------ attention */

@@ -366,3 +366,19 @@ def test_adamw_clip_ema_matches_torch(K):
     torch.nn.utils.clip_grad_norm_([pr2], 1.0)
     opt2.step()
     assert_close(po, pr2.detach(), 1e-6, "oracle adamw", atol_frac=1e-7)
+
+
+def test_gn_silu_bwd_fused_column_sums():
+    """dm_gn_silu_bwd(dx_colsum=...): per-sample channel sums of the written dx, accumulated (+=) in the same pass."""
+    from diffusion_model_amd import kernels as K
+    torch.manual_seed(3)
+    B, H, W, C, G = 3, 12, 10, 64, 8
+    x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
+    gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    _, stats = K.gn_silu_fwd(x, gam, bet, G)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    cs = torch.full((B, C), 0.5, device="cuda")
+    dx = K.gn_silu_bwd(x, dy, gam, bet, stats, G, dg, db, drop_p=0.1, drop_seed=7, colsum_out=cs)
+    ref = dx.float().sum(dim=(1, 2)) + 0.5
+    assert torch.allclose(cs, ref, rtol=1e-4, atol=1e-3), float((cs - ref).abs().max())
