@@ -58,6 +58,7 @@ _SIGS = {
     "dm_last_hip_error": (C.c_char_p, []),
     "dm_note_hip_error": (None, [c_int]),
     "dm_packed_weight_bytes": (c_long, [c_int, c_int, c_int]),
+    "dm_pack_weights_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "dm_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dm_conv3x3": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "dm_gemm": (c_int, [C.POINTER(GemmArgs), c_void_p]),

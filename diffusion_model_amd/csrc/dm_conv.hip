@@ -546,11 +546,12 @@ int dispatch_gemm_stream(const ConvParams& p, hipStream_t st) {
 //   transpose = 0: value = W[n][k][kh][kw]          (forward; W is [N][K][kh][kw] fp32)
 //   transpose = 1: value = W[k][n][2-kh][2-kw]      (data-gradient; W is [K][N][kh][kw])
 // Out-of-range n (>= N) or k (>= K) pack as zero (padding to 16 / 64).
-__global__ void pack_weight_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int N, int K,
-                                   int taps, int transpose, int Npad, int Kpad) {
+__device__ __forceinline__ void pack_weight_range(const float* __restrict__ w, bf16* __restrict__ dst, int N, int K,
+                                                  int taps, int transpose, long first, long stride) {
+  const int Npad = (N + 15) / 16 * 16, Kpad = (K + 63) / 64 * 64;
   const long total = (long)Npad * Kpad * taps;
   const int NTG = Npad >> 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += stride) {
     const int j = (int)(i & 7);
     const int ln = (int)((i >> 3) & 63);
     long r = i >> 9;
@@ -570,6 +571,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16* __restrict
   }
 }
 
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int N, int K,
+                                   int taps, int transpose) {
+  pack_weight_range(w, dst, N, K, taps, transpose, (long)blockIdx.x * blockDim.x + threadIdx.x,
+                    (long)gridDim.x * blockDim.x);
+}
+
+// All shadows of a model in ONE launch (after every optimizer step): block -> table entry by binary search
+// over block_begin.
+__global__ void pack_weight_batch_kernel(const dm_pack_desc* __restrict__ d, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dm_pack_desc e = d[lo];
+  pack_weight_range(e.w, (bf16*)e.dst, e.N, e.K, e.taps, e.transpose,
+                    (long)(blockIdx.x - e.block_begin) * blockDim.x + threadIdx.x, (long)e.nblocks * blockDim.x);
+}
+
 }  // namespace
 
 extern "C" long dm_packed_weight_bytes(int N, int K, int taps) {
@@ -584,7 +604,14 @@ extern "C" int dm_pack_weight(const float* w, void* dst, int N, int K, int taps,
   const long total = (long)Npad * Kpad * taps;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16*)dst, N, K,
-                     taps, transpose, Npad, Kpad);
+                     taps, transpose);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_pack_weights_batch(const dm_pack_desc* table_dev, int n, int total_blocks, dm_stream_t stream) {
+  DM_REQUIRE(table_dev && n > 0 && total_blocks > 0);
+  hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

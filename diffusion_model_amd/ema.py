@@ -19,6 +19,7 @@ class ModelEmaV2(nn.Module):
         super().__init__()
         for m in model.modules():  # packed bf16 shadows are caches, not state: do not deep-copy them
             m.__dict__.pop("_dm_pw", None)
+            m.__dict__.pop("_dm_pack_table", None)
         self.module = deepcopy(model)
         self.module.eval()
         self.decay = decay

@@ -150,6 +150,11 @@ def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0
     check(L.dm_wgrad(C.byref(a), _stream()), "dm_wgrad")
 
 
+def pack_weights_batch(table: torch.Tensor, n: int, total_blocks: int) -> None:
+    """table: device uint8 tensor holding n dm_pack_desc entries (include/dm_hip.h)."""
+    check(_lib.lib().dm_pack_weights_batch(_p(table), int(n), int(total_blocks), _stream()), "dm_pack_weights_batch")
+
+
 # Weight gradients are off the backward critical path (nothing downstream in the same backward reads
 # them), so the UNet enqueues them on a side HIP stream: they fill the CUs that the data-gradient chain
 # (dgrad convs, GroupNorm / attention backward: HBM- or VALU-bound) leaves idle.  join_side() makes the

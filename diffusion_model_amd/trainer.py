@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .unet import Grads, invalidate_packed_weights
+from .unet import Grads, invalidate_packed_weights, repack_all
 
 
 def lr_lambda(step: int, total_steps: int) -> float:
@@ -224,6 +224,7 @@ class Trainer:
         self.sched_step += 1
         self.fp.grad.zero_()
         invalidate_packed_weights()
+        repack_all(self.model)  # all bf16 shadows of the updated weights in one launch
 
     def grad_norm(self) -> float:
         return float(self.norm[0].item())

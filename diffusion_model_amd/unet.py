@@ -73,6 +73,47 @@ class PW:
         return self._bwd
 
 
+def repack_all(model: nn.Module) -> None:
+    """Rebuild every packed shadow the model has used so far in ONE launch (dm_pack_weights_batch) and mark
+    them current.  Called by the trainer right after the fused optimizer step; shadows that do not exist yet
+    are still packed lazily on first use."""
+    entries = []
+    for m in model.modules():
+        pw = m.__dict__.get("_dm_pw")
+        if pw is None:
+            continue
+        if pw._fwd is not None:
+            entries.append((pw, False, pw._fwd))
+        if pw._bwd is not None:
+            entries.append((pw, True, pw._bwd))
+    if not entries:
+        return
+    sig = tuple((pw.c.weight.data_ptr(), buf.data_ptr(), tr) for pw, tr, buf in entries)
+    cached = model.__dict__.get("_dm_pack_table")
+    if cached is None or cached[0] != sig:
+        import numpy as np
+        dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("N", "<i4"), ("K", "<i4"), ("taps", "<i4"), ("tr", "<i4"),
+                       ("bb", "<i4"), ("nb", "<i4")])
+        tab = np.zeros(len(entries), dtype=dt)
+        blk = 0
+        for i, (pw, tr, buf) in enumerate(entries):
+            N, Kd = (pw.k, pw.n) if tr else (pw.n, pw.k)
+            total = ((N + 15) // 16 * 16) * ((Kd + 63) // 64 * 64) * pw.taps
+            nb = min((total + 255) // 256, 1024)
+            tab[i] = (pw.c.weight.data_ptr(), buf.data_ptr(), N, Kd, pw.taps, int(tr), blk, nb)
+            blk += nb
+        dev = entries[0][2].device
+        table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        cached = (sig, table, len(entries), blk)
+        model.__dict__["_dm_pack_table"] = cached
+    K.pack_weights_batch(cached[1], cached[2], cached[3])
+    for pw, tr, _ in entries:
+        if tr:
+            pw._kb = pw._key()
+        else:
+            pw._kf = pw._key()
+
+
 class Grads:
     """Parameter -> fp32 gradient buffer that the wgrad kernels accumulate (+=) into."""
 

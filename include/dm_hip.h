@@ -46,6 +46,15 @@ long dm_packed_weight_bytes(int N, int K, int taps);
  * Replaces: the implicit weight reads of nn.Conv2d / nn.Linear (unet.py:74-75,79,113-114,
  * 160-163,225,234,261,317-320,333-335). */
 int dm_pack_weight(const float* w, void* dst, int N, int K, int taps, int transpose, dm_stream_t stream);
+/* The same for a whole table of weights in ONE launch (the repack after every optimizer step,
+ * main_stl10.py:509).  The table lives in DEVICE memory; entry i owns blocks [block_begin, block_begin+nblocks)
+ * of the launch (256 threads each, ascending, contiguous from 0), total_blocks = their sum. */
+typedef struct dm_pack_desc {
+  const float* w; void* dst;
+  int N, K, taps, transpose;      /* as in dm_pack_weight */
+  int block_begin, nblocks;
+} dm_pack_desc;
+int dm_pack_weights_batch(const dm_pack_desc* table_dev, int n, int total_blocks, dm_stream_t stream);
 
 /* ------------------------------------------------------------------ convolution / GEMM */
 typedef struct dm_conv_args {
