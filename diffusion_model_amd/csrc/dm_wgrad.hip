@@ -394,9 +394,13 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   const long total = (long)pl.ncot * pl.ncit * a->taps * 1024;  // float4 items
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  int groups = pl.nsplit / 16;  // every group sums >= 16 slabs in registers; few atomics per element
-  if (groups < 1) groups = 1;
+  // Split groups trade load parallelism against memory-side fp32 atomics (one per group and element), whose
+  // cost grows with the element count: measured best is a budget of about 300 k atomics per launch.
+  const long elems = (long)pl.ncot * pl.ncit * a->taps * 4096;
+  int groups = (int)(300000 / elems);
   if (groups > 8) groups = 8;
+  if (groups > pl.nsplit / 16) groups = pl.nsplit / 16;
+  if (groups < 1) groups = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
                      pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
   DM_LAUNCH_CHECK();
