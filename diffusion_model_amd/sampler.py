@@ -103,14 +103,17 @@ class CFGSampler:
         ctx = torch.cat([table[torch.full_like(labels, self.uncond_id)], table[labels]]).contiguous()
         z = z.contiguous().clone()
         zz = torch.empty((2 * S, *z.shape[1:]), dtype=torch.float32, device=dev)
-        for t in range(T - 1, -1, -1):
-            if t < t_stop:
-                return z
+        tt = torch.empty((2 * S,), dtype=torch.long, device=dev)
+        steps = [t for t in range(T - 1, -1, -1) if t >= t_stop]
+        # every step's coefficient rows in one upload (host fp32 math identical to the reference's)
+        coefs = torch.stack([step_coefficients(beta, abar, t, g, eta, S, final=(t == 0)) for t in steps]).to(dev)
+        # (Replaying the forward as a captured HIP graph was measured: 7.56 vs 7.28 ms/step eager at B=176 -- the
+        # loop is GPU-bound, so the launches stay eager.)
+        for i, t in enumerate(steps):
             final = (t == 0)
-            coef = step_coefficients(beta, abar, t, g, eta, S, final=final).to(dev, non_blocking=True)
             zz[:S].copy_(z)
             zz[S:].copy_(z)
-            tt = torch.full((2 * S,), t, dtype=torch.long, device=dev)
+            tt.fill_(t)
             v, _ = model._fwd(zz, tt, ctx)
             noise = None
             if (not final) and t > 1 and eta > 0.0:
@@ -120,5 +123,5 @@ class CFGSampler:
                     noise = torch.randn(z.shape, dtype=torch.float32, device=dev, generator=generator)
             else:
                 noise = z  # unused (coef[4] == 0)
-            z = K.cfg_ddpm_step(z, v[:S], v[S:], noise, coef)
+            z = K.cfg_ddpm_step(z, v[:S], v[S:], noise, coefs[i])
         return z
