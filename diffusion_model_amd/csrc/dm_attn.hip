@@ -19,7 +19,8 @@
 
 namespace {
 
-constexpr int RS = 80;         // LDS row stride (bytes) of a [rows][32 d] bf16 block (64 B + 16 pad)
+constexpr int RS = 96;         // LDS row stride (bytes) of a [rows][32 d] bf16 block: 64 B + 32 pad makes the ds_read_b128 lane groups
+                               // ({0-3,12-15,20-27},...) and the ds_read_b64_tr_b16 halves conflict-free (80 B is 2-way on both)
 constexpr float NEG = -1e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -31,7 +32,8 @@ struct AttnParams {
   float* delta;
   int B, H, Nq, Nk, hd;
   float scale;
-  uint32_t seed; uint32_t thresh; float inv_keep;  // dm_common.h dropout convention
+  uint32_t seed; uint32_t thresh; float inv_keep;  // dm_common.h dropout convention; thresh = 2*t15
+  uint32_t t15, tm1x2; float keep;  // flash kernels: 15-bit threshold, (t15-1) in both halves, 1-p
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
@@ -73,29 +75,114 @@ __device__ __forceinline__ u32x4 load_piece(const bf16* base, long ld, long tok0
 __device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
   *reinterpret_cast<u32x4*>(dst + (tid >> 2) * RS + (tid & 3) * 16) = v;
 }
+// A staged block PAIR (K+V, or Q+dO) in registers.  Head dims <= 16 (DT == 1) fill only two 16-byte pieces per
+// row, so the 256 threads cover both tensors with ONE load each (threads 0-127 the first tensor, 128-255 the
+// second) and bytes 32.. of the LDS rows are never written -- nor read: every row read of that variant stays
+// inside bytes 0..31.  Head dim 32 takes two loads per thread.
+template <int DT> struct Stage { u32x4 a, b; };
+template <int DT>
+__device__ __forceinline__ void stage_load(Stage<DT>& s, const bf16* A, long lda, const bf16* B, long ldb, long tok0,
+                                           long n_tok, int hoff, int hd, int tid) {
+  if constexpr (DT == 1) {
+    const bool second = tid >= 128;
+    const int row = (tid & 127) >> 1, pc = tid & 1;
+    const bf16* base = second ? B : A;
+    const long ld = second ? ldb : lda;
+    const bool ok = (tok0 + row < n_tok) && (pc * 8 < hd);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? (tok0 + row) * ld + hoff + pc * 8 : 0));
+    s.a = ok ? v : u32x4{0u, 0u, 0u, 0u};
+  } else {
+    s.a = load_piece(A, lda, tok0, n_tok, hoff, hd, tid);
+    s.b = load_piece(B, ldb, tok0, n_tok, hoff, hd, tid);
+  }
+}
+template <int DT>
+__device__ __forceinline__ void stage_store(const Stage<DT>& s, char* sA, char* sB, int tid) {
+  if constexpr (DT == 1) {
+    *reinterpret_cast<u32x4*>((tid >= 128 ? sB : sA) + ((tid & 127) >> 1) * RS + (tid & 1) * 16) = s.a;
+  } else {
+    store_piece(sA, tid, s.a);
+    store_piece(sB, tid, s.b);
+  }
+}
+
+// ---------------------------------------------------------------- shared pieces of the flash kernels
+// With head dims this small the loops are bound by VALU issue, so per-element work is moved into the MFMAs,
+// whose pipe is two-thirds idle:
+//  (1) The lane-owned score operand (the query in fwd / bwd_q, the key in bwd_kv) is pre-multiplied by
+//      c = scale*log2(e) in fp32 and split into bf16 hi + lo parts, so the MFMA returns c*s to ~2^-17.  With
+//      head dims <= 16 the lo part rides in k-slots 16..31 of the 16x16x32 MFMA, which zero padding would
+//      waste (the LDS-side operand re-reads d 0..15 there); with head dim 32 it is a second MFMA.
+//  (2) The accumulator starts at -m (fwd: the running reference maximum) or -LSE (bwd), so the probability
+//      is exp2(acc) with no per-element fma; dP leaves its MFMA as dP - delta*keep the same way.
+//  (3) fwd rescales lazily: the reference maximum of a query moves only when a block exceeds it by more than
+//      2^TAU (wave-uniform branch), so the common block does max / exp / add / pack and nothing else.
+//  (4) Dropout compares 15-bit fields (row word ^ column word, both pre-masked): fwd builds the keep mask of
+//      a key PAIR with v_pk_sub_i16 + v_pk_ashrrev_i16 and ANDs it onto the packed bf16 pair; the backward
+//      kernels compare 16-bit halves in place (SDWA operand select, no shifts).
+constexpr uint32_t M15 = 0x7FFF7FFFu;
+constexpr float TAU = 8.f;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t keepmask15x2(uint32_t x, uint32_t tm1x2) {
+  const s16x2 d = __builtin_bit_cast(s16x2, tm1x2) - __builtin_bit_cast(s16x2, x);  // < 0 iff field >= t15
+  return __builtin_bit_cast(uint32_t, d >> 15);
+}
+__device__ __forceinline__ bool keep15(uint32_t x, int hi, uint32_t t15) {
+  return (uint16_t)(hi ? (x >> 16) : x) >= (uint16_t)t15;
+}
+template <int DT>
+__device__ __forceinline__ void load_scaled_frag(const bf16* base, long ld, long tok, bool tok_ok, int hoff, int hd,
+                                                 int g, float c, bf16x8& f0, bf16x8& f1) {
+  const bf16x8 raw = load_row_frag(base, ld, tok, tok_ok, hoff, hd, DT == 1 ? (g & 1) : g);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s = c * (float)raw[j];
+    hi[j] = (bf16)s;
+    lo[j] = (bf16)(s - (float)hi[j]);
+  }
+  if (DT == 1) { f0 = g < 2 ? hi : lo; f1 = f0; } else { f0 = hi; f1 = lo; }
+}
+template <int DT>
+__device__ __forceinline__ f32x4 score_mfma(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x4 init) {
+  f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, init, 0, 0, 0);
+  if (DT == 2) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, s, 0, 0, 0);
+  return s;
+}
 
 // ---------------------------------------------------------------- forward
-// DROP and EDGE (Nk not a multiple of 64: key-range masks, applied in every block of that rarer variant) are compile-time: the compiler if-converts runtime
-// `if (p.thresh)` / `if (edge)` guards into unconditional hash + select code, which the eval path then pays for.
+// DROP and EDGE (Nk not a multiple of 64: key-range masks, applied in every block of that rarer variant) are
+// compile-time: the compiler if-converts runtime `if (p.thresh)` / `if (edge)` guards into unconditional hash +
+// select code, which the eval path then pays for.
 template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];  // dropout column words of the staged key block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const float c = p.scale * LOG2E;
   const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
 
-  bf16x8 qf[2];
+  bf16x8 qf0[2], qf1[2];
   int qi[2];
+  uint32_t rs[2] = {0u, 0u};
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qi[qt] = q0 + qt * 16 + li;
-    qf[qt] = load_row_frag(p.q, p.ldq, qbase + qi[qt], qi[qt] < p.Nq, hoff, p.hd, g);
+    load_scaled_frag<DT>(p.q, p.ldq, qbase + qi[qt], qi[qt] < p.Nq, hoff, p.hd, g, c, qf0[qt], qf1[qt]);
+    if constexpr (DROP) rs[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
   }
-  float m[2] = {NEG, NEG}, l[2] = {0.f, 0.f};
+  float m[2] = {0.f, 0.f};  // reference maximum (exp2 domain), set by the first block
+  // row sums of P ride on the MFMA pipe too: an all-ones A operand makes every row of lacc the sum over the
+  // block's keys of the (bf16, undropped) probabilities -- no per-element add, no cross-lane reduction
+  f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.f;
   f32x4 acc[DT][2];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -105,38 +192,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   const int nkb = (p.Nk + 63) / 64;
   // K/V blocks are prefetched two blocks ahead into registers and one block ahead into the other LDS
   // buffer: one barrier per key block, no exposed global latency.
-  u32x4 rk0, rv0, rk1 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
-  rk0 = load_piece(p.k, p.ldk, kbase, kbase + p.Nk, hoff, p.hd, tid);
-  rv0 = load_piece(p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
-  if (nkb > 1) {
-    rk1 = load_piece(p.k, p.ldk, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
-    rv1 = load_piece(p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
-  }
-  store_piece(sKb[0], tid, rk0);
-  store_piece(sVb[0], tid, rv0);
-  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid);
+  Stage<DT> r0, r1;
+  stage_load<DT>(r0, p.k, p.ldk, p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  r1 = r0;
+  if (nkb > 1) stage_load<DT>(r1, p.k, p.ldk, p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  stage_store<DT>(r0, sKb[0], sVb[0], tid);
+  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
   __syncthreads();
-  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    if (kb + 2 < nkb) {
-      rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
-      rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
-    }
+  auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
+    if (kb + 2 < nkb) stage_load<DT>(r_free, p.k, p.ldk, p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
-    f32x4 st[4][2];
+    f32x4 st[4][2];  // c*s - m, straight out of the MFMA
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + gk * 16);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int qt = 0; qt < 2; ++qt) {
+        const float nm = -m[qt];
+        st[kt][qt] = score_mfma<DT>(kf, qf0[qt], qf1[qt], f32x4{nm, nm, nm, nm});
+      }
     }
-    // Per-element VALU budget (the bound of these small-head kernels): max, fma, v_exp, add, half a
-    // cvt_pk.  The key-range mask is applied only in the last, partial key block; the softmax scale
-    // rides in the fma; v_exp_f32 is issued raw (no denormal range fix-up: p < 2^-126 is 0 anyway).
+    float bm[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float bm = NEG;
       if constexpr (EDGE) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -144,39 +223,58 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
           for (int r = 0; r < 4; ++r)
             if (kb * 64 + kt * 16 + 4 * g + r >= p.Nk) st[kt][qt][r] = NEG;
       }
+      float t = NEG;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bm = fmaxf(bm, st[kt][qt][r]);
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m[qt], bm * c);
-      const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
-      m[qt] = mn;
-      float ps = 0.f;
-      uint32_t rs = 0u;
-      if constexpr (DROP) rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        uint32_t db0 = 0u, db1 = 0u;
-        if constexpr (DROP) {
-          const u32x2 cw = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + kt * 8 + 2 * g);
-          db0 = rs ^ cw[0]; db1 = rs ^ cw[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][qt][r], c, -mn));
-          ps += pv;
-          if constexpr (DROP) pv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? pv : 0.f;
-          st[kt][qt][r] = pv;
-        }
-      }
-      l[qt] = l[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc[dt][qt] *= alpha;
+        for (int r = 0; r < 4; ++r) t = fmaxf(t, st[kt][qt][r]);
+      t = fmaxf(t, __shfl_xor(t, 16, 64));
+      bm[qt] = fmaxf(t, __shfl_xor(t, 32, 64));
     }
+    // lazy rescale: move a query's reference maximum only in the first block or when this block tops it by > TAU
+    const bool first = kb == 0;
+    if (__builtin_amdgcn_ballot_w64(first || bm[0] > TAU || bm[1] > TAU) != 0ull) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float sh = (first || bm[qt] > TAU) ? bm[qt] : 0.f;
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-sh);  // first block: l = acc = 0 (and -sh may be huge)
+        m[qt] += sh;
+        lacc[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt][qt] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kt][qt][r] -= sh;
+      }
+    }
+    // Per-element VALU budget (the bound of these small-head kernels): half a max3, v_exp, half a cvt_pk
+    // (+ with dropout half each of xor, pk_sub, pk_ashr, and).  v_exp_f32 is issued raw (no denormal range
+    // fix-up: p < 2^-126 is 0 anyway).
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][qt][r] = __builtin_amdgcn_exp2f(st[kt][qt][r]);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pb[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        pb[qt] = pack8(st[2 * ks][qt], st[2 * ks + 1][qt]);
+        lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
+        if constexpr (DROP) {
+          const u32x2 ca = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + (2 * ks) * 8 + 2 * g);
+          const u32x2 cb = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + (2 * ks + 1) * 8 + 2 * g);
+          u32x4 w = __builtin_bit_cast(u32x4, pb[qt]);
+          w[0] &= keepmask15x2(rs[qt] ^ ca[0], p.tm1x2);
+          w[1] &= keepmask15x2(rs[qt] ^ ca[1], p.tm1x2);
+          w[2] &= keepmask15x2(rs[qt] ^ cb[0], p.tm1x2);
+          w[3] &= keepmask15x2(rs[qt] ^ cb[1], p.tm1x2);
+          pb[qt] = __builtin_bit_cast(bf16x8, w);
+        }
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int qq = li >> 2, pp = li & 3;
@@ -184,26 +282,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
         const bf16x8 vT = tr_pair(a0, a0 + 16 * RS);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, pack8(st[2 * ks][qt], st[2 * ks + 1][qt]),
-                                                                acc[dt][qt], 0, 0, 0);
+          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, pb[qt], acc[dt][qt], 0, 0, 0);
       }
     }
     if (kb + 1 < nkb) {
-      store_piece(sKb[(kb + 1) & 1], tid, rk_next);
-      store_piece(sVb[(kb + 1) & 1], tid, rv_next);
-      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid));
+      stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
+      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };
   for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
+    block(kb, r0, r1);
+    if (kb + 1 < nkb) block(kb + 1, r1, r0);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float lt = l[qt];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    const float lt = lacc[qt][0];
     const float inv = (DROP ? p.inv_keep : 1.f) / lt;  // the dropout rescale rides in the normalisation
     if (qi[qt] < p.Nq) {
       if (g == 0 && p.lse) p.lse[(long)bh * p.Nq + qi[qt]] = (m[qt] + log2f(lt)) * LN2;
@@ -243,45 +337,59 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 }
 
 // dK, dV: one wave = 16 keys (MFMA columns), workgroup = 64 keys, loop over query blocks of 64.
+// With dropout mask Z and keep = 1-p:  dS = P o (Z o dP / keep - delta) = (P o (Z o dP - delta*keep)) / keep;
+// the 1/keep rides in the dK epilogue, delta*keep in the dP accumulator's start value.
 template <int DT, bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];
-  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][64];  // per-query dropout row state
+  __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];  // -LSE*log2e, -delta*keep
+  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][128];  // per-query dropout row words: [0..63] as is, [64..127] >> 16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int key = blockIdx.x * 64 + wave * 16 + li;
   const bool key_ok = key < p.Nk;
   const float c = p.scale * LOG2E;
   const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
-  const bf16x8 kfrag = load_row_frag(p.k, p.ldk, kbase + key, key_ok, hoff, p.hd, g);
+  bf16x8 kf0, kf1;
+  load_scaled_frag<DT>(p.k, p.ldk, kbase + key, key_ok, hoff, p.hd, g, c, kf0, kf1);
   const bf16x8 vfrag = load_row_frag(p.v, p.ldv, kbase + key, key_ok, hoff, p.hd, g);
   f32x4 dkT[DT], dvT[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqb = (p.Nq + 63) / 64;
-  const uint32_t cw = DROP ? dm_attn_colword(p.seed, (uint32_t)key >> 1) : 0u;  // this lane's key pair
+  // this lane's 15-bit column field, in the low half; the row words come from the matching half-array of sRb
+  uint32_t cwl = 0u;
+  if constexpr (DROP) {
+    const uint32_t cw = dm_attn_colword(p.seed, (uint32_t)key >> 1) & M15;
+    cwl = (key & 1) ? (cw >> 16) : cw;
+  }
+  const int rpar = (key & 1) * 64;
+  const float keepf = DROP ? p.keep : 1.f;
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
-  struct Regs { u32x4 q, o; float l, d; uint32_t rs; };
+  struct Regs { Stage<DT> st; float l, d; uint32_t rs; };
   auto fetch = [&](int qb, Regs& r) {
-    r.q = load_piece(p.q, p.ldq, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
-    r.o = load_piece(p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
-    const int q = qb * 64 + (tid & 63);
-    const bool ok = q < p.Nq;
-    const long li_ = (long)bh * p.Nq + (ok ? q : 0);
-    const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
-    r.l = ok ? lv : 1e30f;  // out-of-range query: p = exp2(-huge) = 0
-    r.d = ok ? dv : 0.f;
-    r.rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+    stage_load<DT>(r.st, p.q, p.ldq, p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
+    if (tid < 64) {  // wave 0 carries the per-query scalars
+      const int q = qb * 64 + tid;
+      const bool ok = q < p.Nq;
+      const long li_ = (long)bh * p.Nq + (ok ? q : 0);
+      const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
+      r.l = ok ? -lv : -1e30f;  // out-of-range query: p = exp2(-huge) = 0
+      r.d = ok ? -dv * keepf : 0.f;
+      if (DROP) r.rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) & M15;
+    }
   };
   auto put = [&](int buf, const Regs& r) {
-    store_piece(sQb[buf], tid, r.q);
-    store_piece(sOb[buf], tid, r.o);
-    if (tid < 64) { sLb[buf][tid] = r.l; sDb[buf][tid] = r.d; sRb[buf][tid] = r.rs; }
+    stage_store<DT>(r.st, sQb[buf], sOb[buf], tid);
+    if (tid < 64) {
+      sLb[buf][tid] = r.l; sDb[buf][tid] = r.d;
+      if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][64 + tid] = r.rs >> 16; }
+    }
   };
-  Regs r0, r1;
+  Regs r0{}, r1{};
   fetch(0, r0);
   if (nqb > 1) fetch(1, r1); else r1 = r0;
   put(0, r0);
@@ -293,30 +401,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     const float* sL = sLb[qb & 1];
     const float* sD = sDb[qb & 1];
     f32x4 pt[4], ds[4];
-    const float ikl = DROP ? p.inv_keep : 1.f;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + g * 16);
-      const bf16x8 da = *reinterpret_cast<const bf16x8*>(sO + (qt * 16 + li) * RS + g * 16);
-      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + gk * 16);
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(sO + (qt * 16 + li) * RS + gk * 16);  // vfrag is zero in k-slots >= hd
       const f32x4 L4 = *reinterpret_cast<const f32x4*>(sL + qt * 16 + 4 * g);
       const f32x4 D4 = *reinterpret_cast<const f32x4*>(sD + qt * 16 + 4 * g);
-      u32x4 R4 = {0u, 0u, 0u, 0u};  // per-query dropout row words
-      if constexpr (DROP) R4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + qt * 16 + 4 * g);
+      const f32x4 s = score_mfma<DT>(qa, kf0, kf1, L4);                        // c*s - LSE
+      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfrag, D4, 0, 0, 0);  // dP - delta*keep
+      u32x4 R4 = {0u, 0u, 0u, 0u};  // per-query dropout row fields
+      if constexpr (DROP) R4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + rpar + qt * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        // no per-element masks: invalid queries carry L = +1e30 (p = 0); invalid keys only pollute their
+        // no per-element masks: invalid queries carry -LSE = -1e30 (p = 0); invalid keys only pollute their
         // own (never stored) dK/dV columns
-        float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L4[r]));
-        float pd = pv, dpv = dp[r];
+        const float pv = __builtin_amdgcn_exp2f(s[r]);
+        float u = pv, t = dp[r];
         if constexpr (DROP) {
-          const bool keep = dm_keep16(R4[r] ^ cw, (uint32_t)key, p.thresh);
-          pd = keep ? pv : 0.f;
-          dpv = keep ? dpv : 0.f;
+          const bool keep = keep15(R4[r] ^ cwl, 0, p.t15);
+          u = keep ? pv : 0.f;
+          t = keep ? t : D4[r];
+          asm("" : "+v"(u));  // keep the select in fp32: one cvt_pk per pair below instead of cvt + select + perm
         }
-        pt[qt][r] = pd;
-        ds[qt][r] = pv * __builtin_fmaf(dpv, ikl, -D4[r]);
+        pt[qt][r] = u;
+        ds[qt][r] = pv * t;
       }
     }
 #pragma unroll
@@ -340,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
     block(qb, r0, r1);
     if (qb + 1 < nqb) block(qb + 1, r1, r0);
   }
-  const float ik = DROP ? p.inv_keep : 1.f;  // dropout rescale of P folded into the dV epilogue
+  const float ik = DROP ? p.inv_keep : 1.f;  // dropout rescale of P (dV) and of dS (dK) folded into the epilogue
   if (key_ok) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -348,7 +456,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
       if (d < p.hd) {
         bf16x4 ok, ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[dt][r] * p.scale); ov[r] = (bf16)(dvT[dt][r] * ik); }
+        for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[dt][r] * (p.scale * ik)); ov[r] = (bf16)(dvT[dt][r] * ik); }
         *reinterpret_cast<bf16x4*>(p.dk + (kbase + key) * p.lddk + hoff + d) = ok;
         *reinterpret_cast<bf16x4*>(p.dv + (kbase + key) * p.lddv + hoff + d) = ov;
       }
@@ -358,26 +466,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kv_kernel(const AttnParams p)
 
 // dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
 template <int DT, bool DROP, bool EDGE>
-__global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const float c = p.scale * LOG2E;
   const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
-  bf16x8 qf[2], dof[2];
+  const float keepf = DROP ? p.keep : 1.f;
+  bf16x8 qf0[2], qf1[2], dof[2];
   int qi[2];
-  float Lq[2], Dq[2];
+  float Lq[2], Dq[2];  // -LSE*log2e, -delta*keep: the MFMA accumulators' start values
+  uint32_t rsq[2] = {0u, 0u};
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qi[qt] = q0 + qt * 16 + li;
     const bool ok = qi[qt] < p.Nq;
-    qf[qt] = load_row_frag(p.q, p.ldq, qbase + qi[qt], ok, hoff, p.hd, g);
+    load_scaled_frag<DT>(p.q, p.ldq, qbase + qi[qt], ok, hoff, p.hd, g, c, qf0[qt], qf1[qt]);
     dof[qt] = load_row_frag(p.d_o, p.lddo, qbase + qi[qt], ok, hoff, p.hd, g);
-    Lq[qt] = ok ? p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : 1e30f;  // out-of-range query: p = 0
-    Dq[qt] = ok ? p.delta[(long)bh * p.Nq + qi[qt]] : 0.f;
+    Lq[qt] = ok ? -p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : -1e30f;  // out-of-range query: p = 0
+    Dq[qt] = ok ? -p.delta[(long)bh * p.Nq + qi[qt]] * keepf : 0.f;
+    if constexpr (DROP) rsq[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
   }
   f32x4 dqT[DT][2];
 #pragma unroll
@@ -385,39 +497,27 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) dqT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nkb = (p.Nk + 63) / 64;
-  u32x4 rk0, rv0, rk1 = {0u, 0u, 0u, 0u}, rv1 = {0u, 0u, 0u, 0u};
-  rk0 = load_piece(p.k, p.ldk, kbase, kbase + p.Nk, hoff, p.hd, tid);
-  rv0 = load_piece(p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
-  if (nkb > 1) {
-    rk1 = load_piece(p.k, p.ldk, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
-    rv1 = load_piece(p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
-  }
-  store_piece(sKb[0], tid, rk0);
-  store_piece(sVb[0], tid, rv0);
-  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid);
+  Stage<DT> r0, r1;
+  stage_load<DT>(r0, p.k, p.ldk, p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  r1 = r0;
+  if (nkb > 1) stage_load<DT>(r1, p.k, p.ldk, p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  stage_store<DT>(r0, sKb[0], sVb[0], tid);
+  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
   __syncthreads();
-  uint32_t rsq[2] = {0u, 0u};
-  if constexpr (DROP) {
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) rsq[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt]));
-  }
-  const float ik = DROP ? p.inv_keep : 1.f;
-  auto block = [&](int kb, u32x4& rk_free, u32x4& rv_free, u32x4& rk_next, u32x4& rv_next) {
-    if (kb + 2 < nkb) {
-      rk_free = load_piece(p.k, p.ldk, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
-      rv_free = load_piece(p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
-    }
+  auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
+    if (kb + 2 < nkb) stage_load<DT>(r_free, p.k, p.ldk, p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 ds[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + g * 16);
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (kt * 16 + li) * RS + g * 16);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kt * 16 + li) * RS + gk * 16);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (kt * 16 + li) * RS + gk * 16);  // dof is zero in k-slots >= hd
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const float nl = Lq[qt], nd = Dq[qt];
+        const f32x4 s = score_mfma<DT>(kf, qf0[qt], qf1[qt], f32x4{nl, nl, nl, nl});
+        const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt], f32x4{nd, nd, nd, nd}, 0, 0, 0);
         uint32_t db0 = 0u, db1 = 0u;
         if constexpr (DROP) {
           const u32x2 cw = *reinterpret_cast<const u32x2*>(sCb[kb & 1] + kt * 8 + 2 * g);
@@ -426,11 +526,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 64 + kt * 16 + 4 * g + r;
-          float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -Lq[qt]));
-          if constexpr (EDGE) { if (key >= p.Nk) pv = 0.f; }  // key-range mask only in the last, partial key block
-          float dpv = dp[r];
-          if constexpr (DROP) dpv = dm_keep16(r < 2 ? db0 : db1, (uint32_t)r, p.thresh) ? dpv : 0.f;
-          ds[kt][qt][r] = pv * __builtin_fmaf(dpv, ik, -Dq[qt]);
+          float pv = __builtin_amdgcn_exp2f(s[r]);
+          if constexpr (EDGE) { if (key >= p.Nk) pv = 0.f; }  // key-range mask only in the rarer ragged variant
+          float t = dp[r];
+          if constexpr (DROP) t = keep15(r < 2 ? db0 : db1, r & 1, p.t15) ? t : nd;
+          ds[kt][qt][r] = pv * t;
         }
       }
       // keep the 16 score / dP MFMA results of later key tiles out of registers (3 waves per SIMD)
@@ -450,16 +550,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
       }
     }
     if (kb + 1 < nkb) {
-      store_piece(sKb[(kb + 1) & 1], tid, rk_next);
-      store_piece(sVb[(kb + 1) & 1], tid, rv_next);
-      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid));
+      stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
+      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };
   for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, rk0, rv0, rk1, rv1);
-    if (kb + 1 < nkb) block(kb + 1, rk1, rv1, rk0, rv0);
+    block(kb, r0, r1);
+    if (kb + 1 < nkb) block(kb + 1, r1, r0);
   }
+  const float osc = p.scale * (DROP ? p.inv_keep : 1.f);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     if (qi[qt] >= p.Nq) continue;
@@ -469,7 +569,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const AttnParams p) 
       if (d < p.hd) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)(dqT[dt][qt][r] * p.scale);
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)(dqT[dt][qt][r] * osc);
         *reinterpret_cast<bf16x4*>(p.dq + (qbase + qi[qt]) * p.lddq + hoff + d) = o;
       }
     }
@@ -677,8 +777,14 @@ int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   p.dk = (bf16*)a->dk; p.lddk = a->lddk; p.dv = (bf16*)a->dv; p.lddv = a->lddv; p.delta = a->delta;
   p.B = a->B; p.H = a->heads; p.Nq = a->Nq; p.Nk = a->Nk; p.hd = a->hd; p.scale = a->scale;
   p.seed = dm_seed32(a->drop_seed);
-  p.thresh = dm_thresh16(a->drop_p);
-  p.inv_keep = dm_inv_keep(a->drop_p);
+  // attention draws 15-bit fields (the flash kernels compare them with packed 16-bit signed arithmetic)
+  uint32_t t15 = a->drop_p > 0.f ? (uint32_t)((double)a->drop_p * 32768.0 + 0.5) : 0u;
+  if (t15 > 32767u) t15 = 32767u;
+  p.t15 = t15;
+  p.tm1x2 = ((t15 - 1u) & 0xFFFFu) * 0x10001u;
+  p.thresh = 2u * t15;  // the same probability as a 16-bit threshold (few-token kernels)
+  p.keep = (32768.f - (float)t15) / 32768.f;
+  p.inv_keep = 32768.f / (32768.f - (float)t15);
   return DM_OK;
 }
 
