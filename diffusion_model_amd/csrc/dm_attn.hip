@@ -62,16 +62,8 @@ __device__ __forceinline__ bf16x8 load_row_frag(const bf16* base, long ld, long 
   if (!tok_ok || 8 * g >= hd) return zero8();
   return *reinterpret_cast<const bf16x8*>(base + tok * ld + hoff + 8 * g);
 }
-// One 64-row x 32 (padded) head-dim block of one head travels global -> registers -> LDS, one 16-byte
-// piece per thread; rows >= n_tok and dims >= hd are zero.  The load is unconditional (offset 0 is
-// always readable) so it can stay in flight across a whole compute phase (software pipelining).
-__device__ __forceinline__ u32x4 load_piece(const bf16* base, long ld, long tok0, long n_tok, int hoff, int hd,
-                                            int tid) {
-  const int row = tid >> 2, pc = tid & 3;
-  const bool ok = (tok0 + row < n_tok) && (pc * 8 < hd);
-  const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? (tok0 + row) * ld + hoff + pc * 8 : 0));
-  return ok ? v : u32x4{0u, 0u, 0u, 0u};
-}
+// One 64-row x 32 (padded) head-dim block of one head travels global -> registers -> LDS, one 16-byte piece per
+// thread (head dim 32: four pieces per row).  Loads are issued two blocks ahead (software pipelining).
 __device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
   *reinterpret_cast<u32x4*>(dst + (tid >> 2) * RS + (tid & 3) * 16) = v;
 }
@@ -80,21 +72,47 @@ __device__ __forceinline__ void store_piece(char* dst, int tid, u32x4 v) {
 // second) and bytes 32.. of the LDS rows are never written -- nor read: every row read of that variant stays
 // inside bytes 0..31.  Head dim 32 takes two loads per thread.
 template <int DT> struct Stage { u32x4 a, b; };
+// The loads go through buffer descriptors (one per tensor, based at this (batch, head) slice): a 32-bit offset
+// per thread, and rows past the end or pieces past the head dim come back as zeros from the range check --
+// no 64-bit address arithmetic and no selects in the block loop.
+template <int DT> struct Stager {
+  __amdgpu_buffer_rsrc_t ra, rb;        // DT == 1: ra is this wave's tensor (waves 0-1 the first, 2-3 the second)
+  uint32_t va, vb, stepa, stepb;        // byte offset of this thread's piece in block 0; bytes per 64-row block
+};
 template <int DT>
-__device__ __forceinline__ void stage_load(Stage<DT>& s, const bf16* A, long lda, const bf16* B, long ldb, long tok0,
-                                           long n_tok, int hoff, int hd, int tid) {
+__device__ __forceinline__ Stager<DT> make_stager(const bf16* A, long lda, const bf16* B, long ldb, long tokbase,
+                                                  int n_tok, int hoff, int hd, int tid, int wave) {
+  Stager<DT> s;
+  constexpr uint32_t OOB = 0x7FFFFFFFu;  // beyond any descriptor's range, also after the block steps are added
   if constexpr (DT == 1) {
-    const bool second = tid >= 128;
-    const int row = (tid & 127) >> 1, pc = tid & 1;
-    const bf16* base = second ? B : A;
+    const bool second = wave >= 2;  // wave-uniform
+    const bf16* base = (second ? B + tokbase * ldb : A + tokbase * lda) + hoff;
     const long ld = second ? ldb : lda;
-    const bool ok = (tok0 + row < n_tok) && (pc * 8 < hd);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? (tok0 + row) * ld + hoff + pc * 8 : 0));
-    s.a = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    s.ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((long)(n_tok - 1) * ld + hd) * 2), 0x00020000);
+    s.rb = s.ra;
+    const int row = (tid & 127) >> 1, pc = tid & 1;
+    s.va = pc * 8 < hd ? (uint32_t)(row * ld * 2 + pc * 16) : OOB;
+    s.vb = s.va;
+    s.stepa = (uint32_t)(64 * ld * 2);
+    s.stepb = s.stepa;
   } else {
-    s.a = load_piece(A, lda, tok0, n_tok, hoff, hd, tid);
-    s.b = load_piece(B, ldb, tok0, n_tok, hoff, hd, tid);
+    s.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + tokbase * lda + hoff), 0,
+                                             (int)(((long)(n_tok - 1) * lda + hd) * 2), 0x00020000);
+    s.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + tokbase * ldb + hoff), 0,
+                                             (int)(((long)(n_tok - 1) * ldb + hd) * 2), 0x00020000);
+    const int row = tid >> 2, pc = tid & 3;
+    s.va = pc * 8 < hd ? (uint32_t)(row * lda * 2 + pc * 16) : OOB;
+    s.vb = pc * 8 < hd ? (uint32_t)(row * ldb * 2 + pc * 16) : OOB;
+    s.stepa = (uint32_t)(64 * lda * 2);
+    s.stepb = (uint32_t)(64 * ldb * 2);
   }
+  return s;
+}
+template <int DT>
+__device__ __forceinline__ void stage_load(Stage<DT>& r, const Stager<DT>& s, int blk) {
+  r.a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.ra, (int)(s.va + blk * s.stepa), 0, 0));
+  if constexpr (DT == 2)
+    r.b = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rb, (int)(s.vb + blk * s.stepb), 0, 0));
 }
 template <int DT>
 __device__ __forceinline__ void stage_store(const Stage<DT>& s, char* sA, char* sB, int tid) {
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];  // dropout column words of the staged key block
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -193,14 +211,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   // K/V blocks are prefetched two blocks ahead into registers and one block ahead into the other LDS
   // buffer: one barrier per key block, no exposed global latency.
   Stage<DT> r0, r1;
-  stage_load<DT>(r0, p.k, p.ldk, p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  const Stager<DT> stg = make_stager<DT>(p.k, p.ldk, p.v, p.ldv, kbase, p.Nk, hoff, p.hd, tid, wave);
+  stage_load<DT>(r0, stg, 0);
   r1 = r0;
-  if (nkb > 1) stage_load<DT>(r1, p.k, p.ldk, p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  if (nkb > 1) stage_load<DT>(r1, stg, 1);
   stage_store<DT>(r0, sKb[0], sVb[0], tid);
-  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
+  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
-    if (kb + 2 < nkb) stage_load<DT>(r_free, p.k, p.ldk, p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+    if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 st[4][2];  // c*s - m, straight out of the MFMA
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
     if (kb + 1 < nkb) {
       stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
-      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
+      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];  // -LSE*log2e, -delta*keep
   __shared__ __attribute__((aligned(16))) uint32_t sRb[2][128];  // per-query dropout row words: [0..63] as is, [64..127] >> 16
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int key = blockIdx.x * 64 + wave * 16 + li;
@@ -369,10 +388,11 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   const int rpar = (key & 1) * 64;
   const float keepf = DROP ? p.keep : 1.f;
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
+  const Stager<DT> stg = make_stager<DT>(p.q, p.ldq, p.d_o, p.lddo, qbase, p.Nq, hoff, p.hd, tid, wave);
   struct Regs { Stage<DT> st; float l, d; uint32_t rs; };
   auto fetch = [&](int qb, Regs& r) {
-    stage_load<DT>(r.st, p.q, p.ldq, p.d_o, p.lddo, qbase + qb * 64, qbase + p.Nq, hoff, p.hd, tid);
-    if (tid < 64) {  // wave 0 carries the per-query scalars
+    stage_load<DT>(r.st, stg, qb);
+    if (wave == 0) {  // wave 0 carries the per-query scalars
       const int q = qb * 64 + tid;
       const bool ok = q < p.Nq;
       const long li_ = (long)bh * p.Nq + (ok ? q : 0);
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   };
   auto put = [&](int buf, const Regs& r) {
     stage_store<DT>(r.st, sQb[buf], sOb[buf], tid);
-    if (tid < 64) {
+    if (wave == 0) {
       sLb[buf][tid] = r.l; sDb[buf][tid] = r.d;
       if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][64 + tid] = r.rs >> 16; }
     }
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
   const int q0 = blockIdx.x * 128 + wave * 32;
@@ -498,14 +518,15 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
     for (int qt = 0; qt < 2; ++qt) dqT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nkb = (p.Nk + 63) / 64;
   Stage<DT> r0, r1;
-  stage_load<DT>(r0, p.k, p.ldk, p.v, p.ldv, kbase, kbase + p.Nk, hoff, p.hd, tid);
+  const Stager<DT> stg = make_stager<DT>(p.k, p.ldk, p.v, p.ldv, kbase, p.Nk, hoff, p.hd, tid, wave);
+  stage_load<DT>(r0, stg, 0);
   r1 = r0;
-  if (nkb > 1) stage_load<DT>(r1, p.k, p.ldk, p.v, p.ldv, kbase + 64, kbase + p.Nk, hoff, p.hd, tid);
+  if (nkb > 1) stage_load<DT>(r1, stg, 1);
   stage_store<DT>(r0, sKb[0], sVb[0], tid);
-  if (DROP && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
+  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
-    if (kb + 2 < nkb) stage_load<DT>(r_free, p.k, p.ldk, p.v, p.ldv, kbase + (kb + 2) * 64, kbase + p.Nk, hoff, p.hd, tid);
+    if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 ds[4][2];
@@ -551,7 +572,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
     }
     if (kb + 1 < nkb) {
       stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
-      if (DROP && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
+      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };

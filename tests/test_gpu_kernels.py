@@ -247,6 +247,30 @@ def test_attention_fwd_bwd(K, B, Nq, Nk, C):
         assert float(dq.float().abs().max()) < 1e-2 * float(gv.abs().max())
 
 
+@pytest.mark.parametrize("B,N,C", [(1, 640, 128), (1, 320, 256)])
+def test_attention_wide_score_range(K, B, N, C):
+    """Scores spread over tens of units (exp2 domain): the forward's lazily moved reference maximum must take its
+    rescale path in later key blocks, and the hi/lo-split scaled operand must keep exp(s - lse) accurate."""
+    heads = 8
+    q = q16(3.0 * rnd(B, N, C, seed=11)).requires_grad_()
+    k = q16(3.0 * rnd(B, N, C, seed=12)).requires_grad_()
+    with torch.no_grad():  # a late key that tops every earlier score of every query of head 0
+        k[:, N - 5, :C // heads] = 6.0 * torch.sign(q[:, :, :C // heads].mean(1))
+    v = q16(rnd(B, N, C, seed=13)).requires_grad_()
+    ref, lse_ref = ref_attn(q, k, v, heads)
+    d_o = q16(rnd(B, N, C, seed=14))
+    gq, gk, gv = torch.autograd.grad(ref, [q, k, v], d_o)
+    qb, kb, vb = (t.detach().to(torch.bfloat16) for t in (q, k, v))
+    o, lse = K.attn_fwd(qb, kb, vb, heads)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert_close(o.float(), ref, BF, "attn o (wide)")
+    assert_close(lse, lse_ref, 2e-3, "lse (wide)", atol_frac=2e-3)
+    dq, dk, dv = K.attn_bwd(qb, kb, vb, o, lse, d_o.to(torch.bfloat16), heads)
+    assert_close(dv.float(), gv, 2e-2, "dv (wide)")
+    assert_close(dq.float(), gq, 2e-2, "dq (wide)")
+    assert_close(dk.float(), gk, 2e-2, "dk (wide)")
+
+
 def test_attention_fused_qkv_views(K):
     B, N, C, heads = 2, 128, 128, 8
     qkv = q16(rnd(B, N, 3 * C, seed=1)).to(torch.bfloat16)
