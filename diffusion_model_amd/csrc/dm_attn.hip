@@ -777,6 +777,78 @@ __global__ void attn_small_finish_kernel(const AttnParams p, const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- one context token (the CLIP table)
+// With a single key the softmax is identically 1 -- exactly, in any arithmetic: exp(s - s) / 1 -- so
+//   o[q] = Z[q,h] * v / keep,   lse[q] = scale * q.k,   dS = P o (dP - delta) = 0  =>  dq = dk = 0,
+//   dv = sum_q Z[q,h] * dO[q] / keep
+// (Z: dropout mask of the one probability per (query, head), same words as the few-token kernels).  These are
+// pure streaming kernels: thread = (query, 8 channels), one 16-byte load and one 16-byte store per element
+// group, no LDS in the loop.
+__device__ __forceinline__ bool onekey_keep(const AttnParams& p, int bh, int q) {
+  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+  return dm_keep16(dm_drop_bits(rs, 0u), 0u, p.thresh);
+}
+__global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p) {
+  const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
+  const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
+  const int sub = p.hd >> 3;  // threads per head: 1, 2 or 4
+  const bf16x8 kr = *reinterpret_cast<const bf16x8*>(p.k + (long)b * p.ldk + c8);
+  const bf16x8 vr = *reinterpret_cast<const bf16x8*>(p.v + (long)b * p.ldv + c8);
+  float kf[8];
+  bf16x8 vs, vz;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { kf[j] = (float)kr[j] * p.scale; vs[j] = (bf16)((float)vr[j] * p.inv_keep); vz[j] = (bf16)0.f; }
+  const bool drop = p.thresh != 0u;
+  const int bh = b * p.H + h;
+  for (int q = blockIdx.x * QPB + qs; q < p.Nq; q += gridDim.x * QPB) {
+    const long row = (long)b * p.Nq + q;
+    if (p.lse) {
+      const bf16x8 qr = *reinterpret_cast<const bf16x8*>(p.q + row * p.ldq + c8);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)qr[j] * kf[j];
+      if (sub >= 2) s += __shfl_xor(s, 1, 64);
+      if (sub >= 4) s += __shfl_xor(s, 2, 64);
+      if ((tid % sub) == 0) p.lse[(long)bh * p.Nq + q] = s;
+    }
+    const bool keep = !drop || onekey_keep(p, bh, q);
+    *reinterpret_cast<bf16x8*>(p.o + row * p.ldo + c8) = keep ? (drop ? vs : vr) : vz;
+  }
+}
+// ws: [2][B][C] fp32 (dK half stays zero from the memset, dV half accumulates), finished by attn_small_finish_kernel
+__global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p, float* __restrict__ ws) {
+  __shared__ float sAcc[256 * 8];
+  const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
+  const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
+  const bool drop = p.thresh != 0u;
+  const int bh = b * p.H + h;
+  float acc[8];
+  bf16x8 vz;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; vz[j] = (bf16)0.f; }
+  for (int q = blockIdx.x * QPB + qs; q < p.Nq; q += gridDim.x * QPB) {
+    const long row = (long)b * p.Nq + q;
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.d_o + row * p.lddo + c8);
+    if (!drop || onekey_keep(p, bh, q)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)d[j];
+    }
+    *reinterpret_cast<bf16x8*>(p.dq + row * p.lddq + c8) = vz;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sAcc[(qs * TPQ * 8) + (tid % TPQ) * 8 + j] = acc[j];
+  __syncthreads();
+  if (tid < C) {
+    float s = 0.f;
+    for (int i = 0; i < QPB; ++i) s += sAcc[i * C + tid];
+    atomicAdd(ws + (long)p.B * C + (long)b * C + tid, s * (drop ? p.inv_keep : 1.f));
+  }
+}
+bool onekey_ok(const AttnParams& p) {
+  const int C = p.H * p.hd;
+  return p.Nk == 1 && C <= 2048 && 256 % (C >> 3) == 0 && (p.ldo & 7) == 0 && (!p.dq || ((p.lddq & 7) == 0 && (p.lddo & 7) == 0));
+}
+
 bool small_ok(const AttnParams& p) {
   const int C = p.H * p.hd;
   return p.Nk <= SMALL_NK && C <= 256 && 256 % p.H == 0 && 256 % C == 0;
@@ -815,6 +887,14 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   AttnParams p{};
   const int rc = fill(p, a, false);
   if (rc != DM_OK) return rc;
+  if (onekey_ok(p)) {
+    const int QPB = 256 / ((p.H * p.hd) >> 3);
+    int gx = (p.Nq + QPB - 1) / QPB;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(attn_onekey_fwd_kernel, dim3(gx, p.B), dim3(256), 0, (hipStream_t)stream, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   if (small_ok(p)) {
     const int C = p.H * p.hd, QB = 256 / p.H;
     const dim3 g((p.Nq + QB * SMALL_CHUNKS - 1) / (QB * SMALL_CHUNKS), p.B);
@@ -842,6 +922,18 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   const int rc = fill(p, a, true);
   if (rc != DM_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (onekey_ok(p)) {
+    const int C = p.H * p.hd, QPB = 256 / (C >> 3);
+    float* ws = p.delta;  // fp32 [2][B,1,C] reduction scratch (the caller sizes it: dm_hip.h)
+    if (hipMemsetAsync(ws, 0, (size_t)2 * p.B * C * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+    int gx = (p.Nq + QPB - 1) / QPB;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(attn_onekey_bwd_kernel, dim3(gx, p.B), dim3(256), 0, st, p, ws);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_small_finish_kernel, dim3(64), dim3(256), 0, st, p, (const float*)ws, C);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   if (small_ok(p)) {
     // p.delta doubles as the fp32 [2][B,Nk,C] reduction scratch (the caller sizes it: dm_hip.h)
     const int C = p.H * p.hd, QB = 256 / p.H;

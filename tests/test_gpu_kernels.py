@@ -280,7 +280,7 @@ def test_attention_fused_qkv_views(K):
     assert_close(o.float(), ref, BF, "attn views")
 
 
-@pytest.mark.parametrize("N,Nk", [(256, 256), (1024, 8)])  # flash path / few-token path
+@pytest.mark.parametrize("N,Nk", [(256, 256), (1024, 8), (1024, 1)])  # flash / few-token / one-token path
 def test_attention_dropout_consistency(K, N, Nk):
     """Dropout masks come from a counter RNG; check keep-rate and that the backward uses the forward's mask
     (dV of a one-hot d_o equals P_drop^T restricted to that column)."""
