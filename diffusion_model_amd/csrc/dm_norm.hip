@@ -11,6 +11,7 @@
 
 namespace {
 
+constexpr int PART_LDS = 512;  // (split, group) partials staged in LDS by the apply kernels
 struct Wf { float n, mean, m2; };
 __device__ __forceinline__ Wf wf_merge(Wf a, Wf b) {
   const float n = a.n + b.n;
@@ -44,8 +45,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 8; ++j) add[j] = chan_add ? chan_add[(long)b * C + c0 + j] : 0.f;
   float s = 0.f, ss = 0.f, cnt = 0.f;
-  for (int pix = p_begin + prow; pix < p_end; pix += ppi) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)b * HW + pix) * ldx + c0);
+  const bf16* xb = x + (long)b * HW * ldx + c0;
+  int pix = p_begin + prow;
+  // four independent 16-byte loads in flight per thread (the blocks are short: latency, not issue, bounds them)
+  for (; pix + 3 * ppi < p_end; pix += 4 * ppi) {
+    bf16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(xb + (long)(pix + u * ppi) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[u][j] + add[j];
+        s += f; ss += f * f;
+      }
+    cnt += 32.f;
+  }
+  for (; pix < p_end; pix += ppi) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float f = (float)v[j] + add[j];
@@ -77,11 +94,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
                                                         float* __restrict__ stats, bf16* __restrict__ y, long ldy,
                                                         int HW, int C, int G, float eps, int nchunk, int act) {
   __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float s_part[PART_LDS * 3];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  // the sample's partial table comes in with one parallel load per thread, not nsplit dependent ones per group
+  const bool staged = nsplit * G <= PART_LDS;
+  if (staged) {
+    for (int i = tid; i < nsplit * G * 3; i += 256) s_part[i] = partial[(long)b * nsplit * G * 3 + i];
+    __syncthreads();
+  }
   if (tid < G) {
     Wf acc = {0.f, 0.f, 0.f};
     for (int s = 0; s < nsplit; ++s) {
-      const float* o = partial + (((long)b * nsplit + s) * G + tid) * 3;
+      const float* o = staged ? s_part + (s * G + tid) * 3 : partial + (((long)b * nsplit + s) * G + tid) * 3;
       Wf w = {o[0], o[1], o[2]};
       acc = wf_merge(acc, w);
     }
@@ -104,16 +128,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
   }
   const int per = (HW + nchunk - 1) / nchunk;
   const int p_begin = chunk * per, p_end = min(HW, p_begin + per);
-  for (int pix = p_begin + prow; pix < p_end; pix += ppi) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)b * HW + pix) * ldx + c0);
+  const bf16* xb = x + (long)b * HW * ldx + c0;
+  bf16* yb = y + (long)b * HW * ldy + c0;
+  auto one = [&](bf16x8 v, int pix) {
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float z = (float)v[j] * sc[j] + sh[j];
       o[j] = (bf16)(act ? dm_silu(z) : z);
     }
-    *reinterpret_cast<bf16x8*>(y + ((long)b * HW + pix) * ldy + c0) = o;
+    *reinterpret_cast<bf16x8*>(yb + (long)pix * ldy) = o;
+  };
+  int pix = p_begin + prow;
+  for (; pix + 3 * ppi < p_end; pix += 4 * ppi) {
+    bf16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(xb + (long)(pix + u * ppi) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], pix + u * ppi);
   }
+  for (; pix < p_end; pix += ppi) one(*reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx), pix);
 }
 
 // ---------------------------------------------------------------- backward
@@ -124,8 +158,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ stats,
-                                                             float* __restrict__ ws, int HW, int C, int G,
-                                                             int nsplit, int act) {
+                                                             float* __restrict__ ws, float* __restrict__ wsg,
+                                                             int HW, int C, int G, int nsplit, int act) {
   __shared__ float red[2][256 * 8 + 8];
   const int b = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
   const int tpp = C >> 3, ppi = 256 / tpp, cpg = C / G;
@@ -141,9 +175,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
   }
   const int per = (HW + nsplit - 1) / nsplit;
   const int p_begin = split * per, p_end = min(HW, p_begin + per);
-  for (int pix = p_begin + prow; pix < p_end; pix += ppi) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)b * HW + pix) * ldx + c0);
-    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + ((long)b * HW + pix) * lddy + c0);
+  const bf16* xb = x + (long)b * HW * ldx + c0;
+  const bf16* db_ = dy + (long)b * HW * lddy + c0;
+  auto one = [&](bf16x8 v, bf16x8 d) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = ((float)v[j] + add[j] - mean) * rstd;
@@ -155,7 +189,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
       }
       s1[j] += dz; s2[j] += dz * xh;
     }
+  };
+  int pix = p_begin + prow;
+  for (; pix + ppi < p_end; pix += 2 * ppi) {  // four independent loads in flight
+    const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx);
+    const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(db_ + (long)pix * lddy);
+    const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(xb + (long)(pix + ppi) * ldx);
+    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(db_ + (long)(pix + ppi) * lddy);
+    one(v0, d0);
+    one(v1, d1);
   }
+  if (pix < p_end)
+    one(*reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx), *reinterpret_cast<const bf16x8*>(db_ + (long)pix * lddy));
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[0][tid * 8 + j] = s1[j]; red[1][tid * 8 + j] = s2[j]; }
   __syncthreads();
@@ -169,35 +214,40 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
     }
     float* o = ws + (((long)b * nsplit + split) * C + c) * 2;
     o[0] = a1; o[1] = a2;
+    // group partials {sum_c gamma*S1, sum_c gamma*S2}: all the apply pass needs (C <= 256: one channel per thread;
+    // the cpg channels of a group sit in consecutive lanes of one wave)
+    float g1 = gamma[c] * a1, g2 = gamma[c] * a2;
+    for (int o2 = cpg >> 1; o2 > 0; o2 >>= 1) { g1 += __shfl_xor(g1, o2, 64); g2 += __shfl_xor(g2, o2, 64); }
+    if ((c % cpg) == 0) {
+      float* og = wsg + (((long)b * nsplit + split) * G + c / cpg) * 2;
+      og[0] = g1; og[1] = g2;
+    }
   }
 }
 
 // pass 2: grid (nchunk, B): dx = rstd * (dz*gamma - m1 - xhat*m2) (+ add_in), optional dropout mask on dx.
-// chunk 0 writes the per-sample channel sums to sums[b][c][2] for the parameter-gradient kernel.
+// The group means m1, m2 come from the reduce pass's (split, group) partials.
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const bf16* __restrict__ x, long ldx, const float* __restrict__ chan_add, const bf16* __restrict__ dy,
     long lddy, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
-    const float* __restrict__ ws, int nsplit, float* __restrict__ sums, const bf16* __restrict__ add_in, long ldadd,
+    const float* __restrict__ wsg, int nsplit, const bf16* __restrict__ add_in, long ldadd,
     bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
     uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum) {
-  __shared__ float s_s1[256], s_s2[256], s_m1[64], s_m2[64];
+  __shared__ float s_s1[256], s_m1[64], s_m2[64];
+  __shared__ float s_part[PART_LDS * 2];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
-  for (int c = tid; c < C; c += 256) {
-    float a1 = 0.f, a2 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const float* o = ws + (((long)b * nsplit + s) * C + c) * 2;
-      a1 += o[0]; a2 += o[1];
-    }
-    s_s1[c] = a1; s_s2[c] = a2;
-    if (chunk == 0) { sums[((long)b * C + c) * 2] = a1; sums[((long)b * C + c) * 2 + 1] = a2; }
+  // group means of the sample from the reduce pass's (split, group) partials: one parallel load per thread
+  const bool staged = nsplit * G <= PART_LDS;
+  if (staged) {
+    for (int i = tid; i < nsplit * G * 2; i += 256) s_part[i] = wsg[(long)b * nsplit * G * 2 + i];
+    __syncthreads();
   }
-  __syncthreads();
   if (tid < G) {
     float m1 = 0.f, m2 = 0.f;
-    for (int k = 0; k < cpg; ++k) {
-      const int c = tid * cpg + k;
-      m1 += gamma[c] * s_s1[c]; m2 += gamma[c] * s_s2[c];
+    for (int s = 0; s < nsplit; ++s) {
+      const float* o = staged ? s_part + (s * G + tid) * 2 : wsg + (((long)b * nsplit + s) * G + tid) * 2;
+      m1 += o[0]; m2 += o[1];
     }
     const float inv = 1.f / ((float)cpg * (float)HW);
     s_m1[tid] = m1 * inv; s_m2[tid] = m2 * inv;
@@ -217,12 +267,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   const int per = (HW + nchunk - 1) / nchunk;
   const int p_begin = chunk * per, p_end = min(HW, p_begin + per);
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // per-(sample, channel) sums of dx (optional output)
-  for (int pix = p_begin + prow; pix < p_end; pix += ppi) {
-    const long gp = (long)b * HW + pix;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + gp * ldx + c0);
-    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + gp * lddy + c0);
-    bf16x8 a8;
-    if (add_in) a8 = *reinterpret_cast<const bf16x8*>(add_in + gp * ldadd + c0);
+  const bf16x8 z8 = {};
+  auto one = [&](bf16x8 v, bf16x8 d, bf16x8 a8, long gp) {
     bf16x8 o;
     uint32_t db[4] = {0u, 0u, 0u, 0u};
     if (drop_thresh) {
@@ -246,6 +292,26 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
       csum[j] += (float)o[j];
     }
     *reinterpret_cast<bf16x8*>(dx + gp * lddx + c0) = o;
+  };
+  int pix = p_begin + prow;
+  for (; pix + ppi < p_end; pix += 2 * ppi) {  // two pixels per iteration: four to six independent loads in flight
+    const long g0 = (long)b * HW + pix, g1 = g0 + ppi;
+    const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(x + g0 * ldx + c0);
+    const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(dy + g0 * lddy + c0);
+    const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(x + g1 * ldx + c0);
+    const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(dy + g1 * lddy + c0);
+    bf16x8 a0 = z8, a1 = z8;
+    if (add_in) {
+      a0 = *reinterpret_cast<const bf16x8*>(add_in + g0 * ldadd + c0);
+      a1 = *reinterpret_cast<const bf16x8*>(add_in + g1 * ldadd + c0);
+    }
+    one(v0, d0, a0, g0);
+    one(v1, d1, a1, g1);
+  }
+  if (pix < p_end) {
+    const long g0 = (long)b * HW + pix;
+    one(*reinterpret_cast<const bf16x8*>(x + g0 * ldx + c0), *reinterpret_cast<const bf16x8*>(dy + g0 * lddy + c0),
+        add_in ? *reinterpret_cast<const bf16x8*>(add_in + g0 * ldadd + c0) : z8, g0);
   }
   if (dx_colsum) {
     // column sums of the written dx: LDS atomics across the block's pixel rows, then one global atomic per
@@ -260,16 +326,26 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   }
 }
 
-// dgamma[c] += sum_b sums[b][c][1] ; dbeta[c] += sum_b sums[b][c][0] ; dchan[b][c] (+)= rstd-scaled? no:
-// d(chan_add)[b][c] = sum_p dx'[b,p,c] which equals rstd*(gamma*S1 - HW*m1 - m2*sum_p xhat) -- computed by caller
-// from dx if needed; here only the affine parameter gradients.
-__global__ void gn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a1 = 0.f, a2 = 0.f;
-  for (int b = 0; b < B; ++b) { a1 += sums[((long)b * C + c) * 2]; a2 += sums[((long)b * C + c) * 2 + 1]; }
-  dgamma[c] += a2; dbeta[c] += a1;
+// dgamma[c] += sum over (sample, split) rows of ws[row][c][1], dbeta[c] += ... [0].  grid (ceil(2C/64), RB): a block
+// owns 64 consecutive floats of the 2C-float rows and R/RB rows (4 row lanes, loads unrolled), and adds its share
+// with one fp32 atomic per float.
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int R, int C) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, f = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
+  const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float a = 0.f;
+  if (f < 2 * C) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) a += ws[(long)r * C * 2 + f];
+  }
+  red[tid] = a;
+  __syncthreads();
+  if (tid < 64 && f < 2 * C) {
+    a = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+    unsafeAtomicAdd(((f & 1) ? dgamma : dbeta) + (f >> 1), a);
+  }
 }
 
 int pick_split(int B, int HW) {
@@ -285,7 +361,7 @@ int pick_split(int B, int HW) {
 extern "C" long dm_gn_workspace_bytes(int B, int HW, int C, int G) {
   const int ns = pick_split(B, HW);
   const long fwd = (long)B * ns * G * 3 * 4;
-  const long bwd = (long)B * ns * C * 2 * 4 + (long)B * C * 2 * 4;
+  const long bwd = (long)B * ns * C * 2 * 4 + (long)B * ns * G * 2 * 4;
   return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -318,18 +394,20 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G) && drop_p >= 0.f && drop_p < 1.f);
   const int ns = pick_split(B, HW);
   float* ws = (float*)workspace;
-  float* sums = ws + (long)B * ns * C * 2;
+  float* wsg = ws + (long)B * ns * C * 2;  // (split, group) partials behind the (split, channel) ones
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
-                     (const bf16*)dy, lddy, gamma, beta, stats, ws, HW, C, G, ns, act_silu);
+                     (const bf16*)dy, lddy, gamma, beta, stats, ws, wsg, HW, C, G, ns, act_silu);
   DM_LAUNCH_CHECK();
   const uint32_t thresh = dm_thresh16(drop_p);
   const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
-                     (const bf16*)dy, lddy, gamma, beta, stats, ws, ns, sums, (const bf16*)add_in, ldadd, (bf16*)dx,
+                     (const bf16*)dy, lddy, gamma, beta, stats, wsg, ns, (const bf16*)add_in, ldadd, (bf16*)dx,
                      lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum);
   DM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, dgamma, dbeta, B, C);
+  const int R = B * ns;
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, R < 16 ? R : 16), dim3(256), 0, st, ws, dgamma, dbeta,
+                     R, C);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
