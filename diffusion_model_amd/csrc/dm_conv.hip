@@ -645,10 +645,12 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   else if (mode == 2 || mode == 3) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
   else { p.Ho = a->H; p.Wo = a->W; }
   DM_REQUIRE(!p.pool2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
-  const bool wide = (a->Cout % 128 == 0);
+  bool wide = (a->Cout % 128 == 0);
 #define DM_GO(TH, TW, S, PITCH, STRIDE, MODE)                                          \
   do {                                                                                 \
     p.tiles_h = (p.Ho + TH - 1) / TH; p.tiles_w = (p.Wo + TW - 1) / TW;                \
+    /* under two rounds of 128-cout workgroups (512 resident) the 64-cout tile fills the CUs better: measured */ \
+    if ((long)p.B * p.tiles_h * p.tiles_w * (a->Cout / 128) < 1024) wide = false;       \
     if (wide) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);            \
     return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
   } while (0)

@@ -225,7 +225,7 @@ def ref_attn(q, k, v, heads):
 
 @pytest.mark.parametrize("B,Nq,Nk,C", [(2, 576, 576, 256), (2, 64, 64, 128), (1, 2304, 2304, 128), (2, 200, 1, 64),
                                        (2, 130, 4, 128), (1, 576, 77, 256), (2, 96, 96, 64),
-                                       (2, 300, 16, 256), (1, 100, 17, 64), (3, 2304, 1, 128)])
+                                       (2, 300, 16, 256), (1, 100, 17, 64), (3, 2304, 1, 128), (2, 130, 1, 256)])
 def test_attention_fwd_bwd(K, B, Nq, Nk, C):
     heads = 8
     q = q16(rnd(B, Nq, C, seed=1)).requires_grad_()
