@@ -335,7 +335,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------- backward
-// delta[bh][q] = sum_d dO[q][d] * O[q][d]
+// delta[bh][q] = sum_d dO[q][d] * O[q][d].  thread = (token, 8 channels): coalesced 16-byte loads of whole rows,
+// the hd/8 threads of a head combine with shuffles.
+__global__ __launch_bounds__(256) void attn_delta_rows_kernel(const AttnParams p) {
+  const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ, sub = p.hd >> 3;
+  const int tid = threadIdx.x, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
+  const long rows = (long)p.B * p.Nq;
+  for (long row = (long)blockIdx.x * QPB + qs; row < rows; row += (long)gridDim.x * QPB) {
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + row * p.ldo + c8);
+    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(p.d_o + row * p.lddo + c8);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += (float)ov[t] * (float)dv[t];
+    if (sub >= 2) s += __shfl_xor(s, 1, 64);
+    if (sub >= 4) s += __shfl_xor(s, 2, 64);
+    if ((tid % sub) == 0) {
+      const long b = row / p.Nq, q = row % p.Nq;
+      p.delta[(b * p.H + h) * p.Nq + q] = s;
+    }
+  }
+}
+// generic shapes: thread = (batch, head, query)
 __global__ void attn_delta_kernel(const AttnParams p) {
   const long total = (long)p.B * p.H * p.Nq;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -952,7 +972,15 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   const long total = (long)p.B * p.H * p.Nq;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
+  const int Cc = p.H * p.hd;
+  if (Cc <= 2048 && 256 % (Cc >> 3) == 0) {
+    const int QPB = 256 / (Cc >> 3);
+    long nb = ((long)p.B * p.Nq + QPB - 1) / QPB;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
+  }
   DM_LAUNCH_CHECK();
   const dim3 gkv((p.Nk + 63) / 64, p.B * p.H), gq((p.Nq + 127) / 128, p.B * p.H);
   const bool edge = (p.Nk & 63) != 0;
