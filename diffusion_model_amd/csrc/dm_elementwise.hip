@@ -127,12 +127,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 }
 
 // out[c] += sum_b in[b][c]
-__global__ void batchsum_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                       int C) {
+  // 64 channels x 4 row lanes per block, row loads unrolled (independent, in flight together), LDS combine
+  __shared__ float red[256];
+  const int tid = threadIdx.x, c = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
   float a = 0.f;
-  for (int b = 0; b < B; ++b) a += in[(long)b * C + c];
-  out[c] += a;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = rl; b < B; b += 4) a += in[(long)b * C + c];
+  }
+  red[tid] = a;
+  __syncthreads();
+  if (tid < 64 && c < C) out[c] += red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
 }
 
 // ---------------------------------------------------------------- diffusion math (fp32 NCHW)
@@ -352,7 +359,7 @@ extern "C" int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, i
 
 extern "C" int dm_batchsum_f32(const float* in, float* out, int B, int C, dm_stream_t stream) {
   DM_REQUIRE(in && out);
-  hipLaunchKernelGGL(batchsum_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, in, out, B, C);
+  hipLaunchKernelGGL(batchsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out, B, C);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
