@@ -16,7 +16,19 @@ from ._lib import AttnArgs, ConvArgs, GemmArgs, WgradArgs, check
 BF16 = torch.bfloat16
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_FORCED_STREAM = [None]  # set by wgrad_side: launch on this raw stream instead of torch's current one
+
+
 def _stream() -> int:
+    """Raw handle of the stream to launch on.  The launch path calls this once per kernel, so it goes through
+    torch's C accessors when they exist (torch.cuda.current_stream() builds a Stream object per call)."""
+    f = _FORCED_STREAM[0]
+    if f is not None:
+        return f
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -28,6 +40,8 @@ def _act(t: torch.Tensor, what: str = "activation") -> int:
     """Validate an NHWC/[M,C] bf16 activation view; return the pixel stride."""
     if not (t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1):
         raise ValueError(f"{what}: need a CUDA bf16 tensor with contiguous channels")
+    if t.is_contiguous():  # the common case, one C call
+        return t.shape[-1]
     ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
     n = 1
     for i in range(t.dim() - 2, -1, -1):  # outer dims must be densely packed over ld
@@ -50,7 +64,7 @@ _WS = {}
 def workspace(nbytes: int, device) -> torch.Tensor:
     """A per-(device, stream) scratch buffer that only ever grows (stable under graph replay once warm).
     Kernels on different streams must not share scratch: the weight-gradient side stream gets its own."""
-    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index if isinstance(device, torch.device) else torch.device(device).index, _stream())
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -165,11 +179,11 @@ _SIDE = {}
 _SIDE_DIRTY = set()
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index or 0
+def _side_stream(device):
+    key = device.index or 0
     st = _SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = (torch.cuda.Stream(device=device), torch.cuda.Event())
         _SIDE[key] = st
     return st
 
@@ -178,10 +192,14 @@ def wgrad_side(x, dy, dw, dbias=None, **kw):
     if not SIDE_WGRAD:
         return wgrad(x, dy, dw, dbias, **kw)
     dev = x.device
-    side = _side_stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
+    side, ev = _side_stream(dev)
+    ev.record()                 # on the current stream: x and dy are complete here
+    side.wait_event(ev)         # (one event object per device is enough: waits are enqueued in host order)
+    _FORCED_STREAM[0] = side.cuda_stream
+    try:
         wgrad(x, dy, dw, dbias, **kw)
+    finally:
+        _FORCED_STREAM[0] = None
     x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
     dy.record_stream(side)
     _SIDE_DIRTY.add(dev.index or 0)
@@ -190,7 +208,7 @@ def wgrad_side(x, dy, dw, dbias=None, **kw):
 def join_side(device=None) -> None:
     key = torch.device(device).index or 0 if device is not None else torch.cuda.current_device()
     if key in _SIDE_DIRTY:
-        torch.cuda.current_stream(key).wait_stream(_SIDE[key])
+        torch.cuda.current_stream(key).wait_stream(_SIDE[key][0])
         _SIDE_DIRTY.discard(key)
 
 
