@@ -398,8 +398,8 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   // cost grows with the element count: measured best is a budget of about 300 k atomics per launch.
   const long elems = (long)pl.ncot * pl.ncit * a->taps * 4096;
   int groups = (int)(300000 / elems);
-  if (groups > 8) groups = 8;
-  if (groups > pl.nsplit / 16) groups = pl.nsplit / 16;
+  if (groups > 32) groups = 32;  // small 1x1 layers: short per-thread load chains matter more than the atomics
+  if (groups > pl.nsplit / 8) groups = pl.nsplit / 8;
   if (groups < 1) groups = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
                      pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
