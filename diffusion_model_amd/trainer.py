@@ -173,7 +173,7 @@ class Trainer:
             return loss  # reference: "continue" -- no backward, no accumulation-counter change
         if self.buckets is not None and last:
             self.model._bwd_hook = self.buckets.launch
-        self.model._bwd(dout, saved, self.grads)
+        self.model._bwd(dout, saved, self.grads, join=last)
         self.model._bwd_hook = None
         self.micro = 0 if last else self.micro + 1
         if last and not self.defer_optimizer:
@@ -210,6 +210,7 @@ class Trainer:
         return self.lr * lr_lambda(self.sched_step, self.total_steps)
 
     def optimizer_step(self) -> None:
+        K.join_side(self.fp.flat.device)  # weight gradients of un-joined micro-batches (side stream)
         if self.buckets is not None:
             self.buckets.wait()
         pre = 1.0 / self.world

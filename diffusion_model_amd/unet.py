@@ -618,7 +618,7 @@ class UNET(HipModule):
         return y, (x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2)
 
     # ------------------------------------------------------------------ hand-scheduled backward
-    def _bwd(self, dout, saved, g: Grads, need_dx=False):
+    def _bwd(self, dout, saved, g: Grads, need_dx=False, join=True):
         x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2 = saved
         L, half = self.num_layers, self.num_layers // 2
         cat = cats[L - 1]
@@ -677,7 +677,8 @@ class UNET(HipModule):
         dh1 = K.silu_bwd(dsh1, h1)
         K.wgrad_side(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
         hook("tail")
-        K.join_side(da_dev)
+        if join:  # join=False: the caller joins before it consumes the gradients (Trainer: before the optimizer step),
+            K.join_side(da_dev)  # so the tail of the weight-gradient stream overlaps the next micro-batch's forward
         return dx
 
     # ------------------------------------------------------------------ public API
