@@ -188,24 +188,42 @@ def _side_stream(device):
     return st
 
 
+_PENDING = []     # weight gradients waiting for the next fork: (x, dy, dw, dbias, kw)
+SIDE_BATCH = 4    # hipStreamWaitEvent costs the host ~14 us: fork once per few weight gradients, not per call
+
+
 def wgrad_side(x, dy, dw, dbias=None, **kw):
+    """Queue a weight gradient for the side stream.  x and dy must not be written again by the caller (the UNet's
+    backward never does: the side stream reads them concurrently with whatever the main stream runs next)."""
     if not SIDE_WGRAD:
         return wgrad(x, dy, dw, dbias, **kw)
-    dev = x.device
+    _PENDING.append((x, dy, dw, dbias, kw))
+    if len(_PENDING) >= SIDE_BATCH:
+        flush_side()
+
+
+def flush_side() -> None:
+    if not _PENDING:
+        return
+    dev = _PENDING[0][0].device
     side, ev = _side_stream(dev)
-    ev.record()                 # on the current stream: x and dy are complete here
+    ev.record()                 # on the current stream: every queued x and dy is complete here
     side.wait_event(ev)         # (one event object per device is enough: waits are enqueued in host order)
     _FORCED_STREAM[0] = side.cuda_stream
     try:
-        wgrad(x, dy, dw, dbias, **kw)
+        for x, dy, dw, dbias, kw in _PENDING:
+            wgrad(x, dy, dw, dbias, **kw)
     finally:
         _FORCED_STREAM[0] = None
-    x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
-    dy.record_stream(side)
+    for x, dy, _, _, _ in _PENDING:
+        x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
+        dy.record_stream(side)
+    _PENDING.clear()
     _SIDE_DIRTY.add(dev.index or 0)
 
 
 def join_side(device=None) -> None:
+    flush_side()
     key = torch.device(device).index or 0 if device is not None else torch.cuda.current_device()
     if key in _SIDE_DIRTY:
         torch.cuda.current_stream(key).wait_stream(_SIDE[key][0])
