@@ -175,11 +175,19 @@ def main():
     for _ in range(a.warmup):
         opt_step()
     barrier()
+    # roofline leg: HIP events around every launch of the dominant MFMA kernel (nearest-x2 + conv3x3 at the
+    # L4.upsample.conv shape) INSIDE the timed steps, on the stream it is launched on
+    from diffusion_model_amd import kernels as K
+    probe = None
+    if not a.no_roofline and rank == 0:
+        probe = {"mode": 2, "H": 48, "cin": 128, "cout": 128, "pairs": []}
+        K.PROBE = probe
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = opt_step()
     barrier()
     dt = time.perf_counter() - t0
+    K.PROBE = None
     if world > 1:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -230,7 +238,10 @@ def main():
     if sampling:
         out["sampling"] = sampling
     if not a.no_roofline:
-        sec, fl = time_dominant_kernel(a.batch, dev)
+        iso_sec, fl = time_dominant_kernel(a.batch, dev)
+        sec = iso_sec
+        if probe and probe["pairs"]:
+            sec = sum(e0.elapsed_time(e1) for e0, e1 in probe["pairs"]) * 1e-3 / len(probe["pairs"])
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # collected in separate rocprofv3 --pmc runs of the same kernel and shape; bench.py cannot run PMC itself)
         traffic = None
@@ -240,7 +251,10 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": fl / sec / PEAK_BF16, "traffic": traffic,
                            "kernel": "conv_mfma_kernel<16,16,1,18,160,8,MODE_UP> (nearest-x2 + conv3x3, B=%d)" % a.batch,
-                           "avg_launch_us": sec * 1e6, "flop_per_launch": fl}
+                           "avg_launch_us": sec * 1e6, "flop_per_launch": fl,
+                           "launches_timed": len(probe["pairs"]) if probe else 0,
+                           "timed_where": "inside the timed training steps (HIP events around each launch)",
+                           "isolated_back_to_back_us": iso_sec * 1e6}
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
