@@ -1,0 +1,90 @@
+"""STL10 input pipeline for ``main_stl10.train(train_loader=...)`` -- SURVEY.md section 8(f) item 1: the data format
+on the input side of the hot path.
+
+The reference reads ``torchvision.datasets.STL10(root='stl10_data', split='train')`` with
+``ToTensor()`` + ``Normalize((0.5,)*3, (0.5,)*3)`` behind a shuffling ``DataLoader`` (utils.py:134-139,
+main_stl10.py:421-432).  torchvision is not part of this package; what is restated here is the published binary
+format of the dataset (``stl10_binary/{train,test,unlabeled}_X.bin``: uint8, one image = 3 x 96 x 96 values stored
+channel-major with each channel COLUMN-major; ``*_y.bin``: uint8 labels 1..10) and the two transforms, as the same
+fp32 operations in the same order (``/255``, ``-0.5``, ``/0.5``), so a batch equals the reference's bit for bit.
+
+MI355X-first: 288 GB of HBM hold the whole split (5000 x 27,648 bytes = 138 MB as uint8), so the loader uploads it
+once and builds every batch on the device with a gather + the elementwise transform -- no worker processes, no
+per-batch PCIe traffic, nothing for the training step to wait on.  Shuffling draws one ``torch.randperm`` per epoch
+from a seeded CPU generator (the reference's DataLoader order is unseeded; order is not part of parity)."""
+from __future__ import annotations
+
+import os
+from typing import Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+IMG_BYTES = 3 * 96 * 96
+_SPLITS = {"train": ("train_X.bin", "train_y.bin"), "test": ("test_X.bin", "test_y.bin"),
+           "unlabeled": ("unlabeled_X.bin", None)}
+
+
+def read_stl10_binary(root: str, split: str = "train") -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """-> (images uint8 [N,3,96,96] in the usual row-major (C,H,W) order, labels int64 [N] in 0..9 or None).
+    ``root`` is the directory that holds ``stl10_binary/`` (the reference's ``stl10_data``) or that directory itself."""
+    if split not in _SPLITS:
+        raise ValueError(f"split must be one of {sorted(_SPLITS)}")
+    xname, yname = _SPLITS[split]
+    base = os.path.join(root, "stl10_binary") if os.path.isdir(os.path.join(root, "stl10_binary")) else root
+    xpath = os.path.join(base, xname)
+    if not os.path.exists(xpath):
+        raise FileNotFoundError(f"{xpath}: STL10 binary files not found (this package never downloads data)")
+    raw = np.fromfile(xpath, dtype=np.uint8)
+    if raw.size == 0 or raw.size % IMG_BYTES:
+        raise ValueError(f"{xpath}: size {raw.size} is not a multiple of {IMG_BYTES}")
+    # stored as [N][C][W][H] (column-major channels): swap the last two axes to get [N][C][H][W]
+    images = np.ascontiguousarray(raw.reshape(-1, 3, 96, 96).transpose(0, 1, 3, 2))
+    labels = None
+    if yname is not None:
+        ypath = os.path.join(base, yname)
+        y = np.fromfile(ypath, dtype=np.uint8)
+        if y.size != images.shape[0]:
+            raise ValueError(f"{ypath}: {y.size} labels for {images.shape[0]} images")
+        if y.min() < 1 or y.max() > 10:
+            raise ValueError(f"{ypath}: labels must be 1..10")
+        labels = y.astype(np.int64) - 1
+    return images, labels
+
+
+def normalize_uint8(x: torch.Tensor) -> torch.Tensor:
+    """ToTensor() then Normalize(0.5, 0.5) of the reference (utils.py:134-137), same fp32 ops in the same order."""
+    return (x.to(torch.float32) / 255.0 - 0.5) / 0.5
+
+
+class STL10Loader:
+    """Iterable of ``(x [B,3,96,96] fp32 in [-1,1], labels [B] int64)`` device batches with ``len()``, the interface
+    ``main_stl10.train`` expects from ``train_loader``.  The split lives on ``device`` as uint8."""
+
+    def __init__(self, root: str = "stl10_data", split: str = "train", batch_size: int = 64, shuffle: bool = True,
+                 drop_last: bool = False, seed: int = 0, device: Optional[torch.device] = None,
+                 rank: int = 0, world_size: int = 1):
+        images, labels = read_stl10_binary(root, split)
+        if labels is None:
+            labels = np.full(images.shape[0], -1, dtype=np.int64)
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.images = torch.from_numpy(images).to(dev)
+        self.labels = torch.from_numpy(labels).to(dev)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
+        self.gen = torch.Generator().manual_seed(int(seed))
+        self.rank, self.world = int(rank), int(world_size)  # data-parallel: every rank takes its stride of the epoch order
+        self.n = images.shape[0]
+
+    def _n_local(self) -> int:
+        return (self.n - self.rank + self.world - 1) // self.world
+
+    def __len__(self) -> int:
+        n = self._n_local()
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        order = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
+        order = order[self.rank::self.world].to(self.images.device)
+        for i in range(len(self)):
+            idx = order[i * self.batch_size:(i + 1) * self.batch_size]
+            yield normalize_uint8(self.images.index_select(0, idx)), self.labels.index_select(0, idx)

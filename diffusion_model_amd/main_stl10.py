@@ -2,11 +2,13 @@
 the HIP hot path.  Same call signatures, same arithmetic per batch, same checkpoint dict
 (``{'weights', 'optimizer', 'ema'}``, main_stl10.py:533-539).
 
-Outside the hot path, on purpose: the torchvision STL10 reader and the matplotlib
-monitoring images.  ``train`` therefore takes the batches from a ``train_loader`` argument (any iterable
-of ``(x[B,3,96,96] in [-1,1], labels[B])`` with ``len()``; a seeded synthetic loader of the same shape is
-used when none is given), and ``inference`` returns the fixed-seed class grid as a tensor instead of
-writing PNGs.  Monitoring hooks can be attached through ``on_epoch_end``."""
+``train`` takes its batches from a ``train_loader`` argument (any iterable of ``(x[B,3,96,96] in [-1,1],
+labels[B])`` with ``len()``).  When none is given it reads the STL10 binary files under ``stl10_data`` with
+``data.STL10Loader`` (device-resident uint8 split, the reference's ToTensor + Normalize restated; torchvision
+itself is not used) and falls back to a seeded synthetic loader of the same shape when the files are absent
+(nothing is ever downloaded).  Outside the hot path, on purpose: the matplotlib
+monitoring images -- ``inference`` returns the fixed-seed class grid as a tensor instead of writing PNGs, and
+monitoring hooks can be attached through ``on_epoch_end``."""
 from __future__ import annotations
 
 import os
@@ -65,8 +67,12 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
     """Reference main_stl10.py:352-545.  Returns ``(model, ema, trainer)``."""
     scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
     if train_loader is None:
-        log("[warn] no train_loader given: the STL10 reader is outside this package's scope; using SyntheticLoader")
-        train_loader = SyntheticLoader()
+        try:  # reference: torchvision STL10(root='stl10_data', split='train'), shuffled, batch_size BATCH_SIZE
+            from .data import STL10Loader
+            train_loader = STL10Loader("stl10_data", "train", batch_size=BATCH_SIZE, shuffle=True, device=device)
+        except FileNotFoundError as exc:
+            log(f"[warn] {exc}; using SyntheticLoader")
+            train_loader = SyntheticLoader()
     if utils.CONTEXT_TABLE is None and os.path.exists(clip_table_path):
         utils._load_clip_context_table(clip_table_path)
         log(f"[info] Loaded CLIP context table from {clip_table_path} with dim {utils.CONTEXT_TABLE.shape[-1]}")

@@ -1,0 +1,81 @@
+"""CPU: the STL10 binary reader and the ToTensor + Normalize restatement on a small synthetic
+file written in the dataset's published layout (uint8, per image 3 channels, each channel column-major; labels
+1..10).  No dataset is downloaded or read from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from diffusion_model_amd.data import STL10Loader, normalize_uint8, read_stl10_binary
+
+
+def write_split(root, n, seed=0, name="train"):
+    rng = np.random.default_rng(seed)
+    imgs = rng.integers(0, 256, size=(n, 3, 96, 96), dtype=np.uint8)      # row-major (C,H,W): what a reader must return
+    labels = rng.integers(0, 10, size=n).astype(np.int64)
+    d = root / "stl10_binary"
+    d.mkdir(parents=True, exist_ok=True)
+    imgs.transpose(0, 1, 3, 2).tofile(d / f"{name}_X.bin")               # on disk every channel is column-major
+    (labels + 1).astype(np.uint8).tofile(d / f"{name}_y.bin")
+    return imgs, labels
+
+
+def test_reader_layout_and_labels(tmp_path):
+    imgs, labels = write_split(tmp_path, 7)
+    x, y = read_stl10_binary(str(tmp_path), "train")
+    assert x.dtype == np.uint8 and x.shape == (7, 3, 96, 96) and np.array_equal(x, imgs)
+    assert y.dtype == np.int64 and np.array_equal(y, labels)
+    x2, _ = read_stl10_binary(str(tmp_path / "stl10_binary"), "train")   # the binary directory itself is accepted too
+    assert np.array_equal(x2, imgs)
+
+
+def test_reader_rejects_bad_files(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        read_stl10_binary(str(tmp_path), "train")
+    write_split(tmp_path, 3)
+    with open(tmp_path / "stl10_binary" / "train_X.bin", "ab") as f:
+        f.write(b"\x00" * 5)
+    with pytest.raises(ValueError):
+        read_stl10_binary(str(tmp_path), "train")
+
+
+def test_normalize_matches_totensor_normalize():
+    u = torch.arange(256, dtype=torch.uint8)
+    ref = (u.float().div(255) - 0.5) / 0.5      # ToTensor(): /255 in fp32; Normalize(0.5, 0.5): (x - mean) / std
+    out = normalize_uint8(u)
+    assert torch.equal(out, ref) and float(out.min()) == -1.0 and float(out.max()) == 1.0
+
+
+def test_loader_epochs_shuffle_and_rank_shards(tmp_path):
+    imgs, labels = write_split(tmp_path, 37, seed=3)
+    ld = STL10Loader(str(tmp_path), "train", batch_size=8, shuffle=True, seed=5)
+    assert len(ld) == 5
+    ref = normalize_uint8(torch.from_numpy(imgs))
+    key = lambda r: tuple(r[:, 0, 0].tolist()) + tuple(r[:, 5, 7].tolist())  # noqa: E731  (a fingerprint per image)
+    index = {key(r): i for i, r in enumerate(ref)}
+    seen = []
+    for x, y in ld:
+        assert x.dtype == torch.float32 and x.shape[1:] == (3, 96, 96) and y.dtype == torch.int64
+        for xi, yi in zip(x, y):  # every image comes back normalised and with its own label
+            i = index[key(xi)]
+            assert torch.equal(xi, ref[i]) and int(yi) == int(labels[i])
+            seen.append(i)
+    assert sorted(seen) == list(range(37))                    # one epoch = every image once
+    assert seen != sorted(seen)                               # ... in shuffled order
+    again = [index[key(xi)] for x, _ in STL10Loader(str(tmp_path), "train", batch_size=8, shuffle=True, seed=5) for xi in x]
+    assert again == seen                                      # the order is a function of the seed
+    # two ranks partition one epoch order without overlap
+    a = STL10Loader(str(tmp_path), "train", batch_size=64, shuffle=True, seed=9, rank=0, world_size=2)
+    b = STL10Loader(str(tmp_path), "train", batch_size=64, shuffle=True, seed=9, rank=1, world_size=2)
+    xa, _ = next(iter(a)); xb, _ = next(iter(b))
+    assert xa.shape[0] + xb.shape[0] == 37
+    got = [index[key(r)] for r in torch.cat([xa, xb])]
+    assert sorted(got) == list(range(37))
+
+
+def test_loader_exact_batches_unshuffled(tmp_path):
+    imgs, labels = write_split(tmp_path, 10, seed=1)
+    ld = STL10Loader(str(tmp_path), "train", batch_size=4, shuffle=False, drop_last=True)
+    assert len(ld) == 2
+    batches = list(ld)
+    assert torch.equal(batches[0][0], normalize_uint8(torch.from_numpy(imgs[:4])))
+    assert torch.equal(batches[1][1], torch.from_numpy(labels[4:8]))
