@@ -9,7 +9,7 @@ channel-major with each channel COLUMN-major; ``*_y.bin``: uint8 labels 1..10) a
 fp32 operations in the same order (``/255``, ``-0.5``, ``/0.5``), so a batch equals the reference's bit for bit.
 
 MI355X-first: 288 GB of HBM hold the whole split (5000 x 27,648 bytes = 138 MB as uint8), so the loader uploads it
-once and builds every batch on the device with a gather + the elementwise transform -- no worker processes, no
+once and builds every batch on the device with a gather + a 256-entry lookup of the transform -- no worker processes, no
 per-batch PCIe traffic, nothing for the training step to wait on.  Shuffling draws one ``torch.randperm`` per epoch
 from a seeded CPU generator (the reference's DataLoader order is unseeded; order is not part of parity)."""
 from __future__ import annotations
@@ -53,8 +53,15 @@ def read_stl10_binary(root: str, split: str = "train") -> Tuple[np.ndarray, Opti
 
 
 def normalize_uint8(x: torch.Tensor) -> torch.Tensor:
-    """ToTensor() then Normalize(0.5, 0.5) of the reference (utils.py:134-137), same fp32 ops in the same order."""
+    """ToTensor() then Normalize(0.5, 0.5) of the reference (utils.py:134-137), same fp32 ops in the same order
+    (on the CPU, where the reference's DataLoader workers run them)."""
     return (x.to(torch.float32) / 255.0 - 0.5) / 0.5
+
+
+def normalize_lut() -> torch.Tensor:
+    """The 256 possible results of normalize_uint8, computed on the CPU: device batches are a table lookup, so they
+    equal the reference's CPU-transformed batches bit for bit (a device-side ``/255`` may round differently)."""
+    return normalize_uint8(torch.arange(256, dtype=torch.int32).to(torch.uint8))
 
 
 class STL10Loader:
@@ -70,6 +77,7 @@ class STL10Loader:
         dev = torch.device(device) if device is not None else torch.device("cpu")
         self.images = torch.from_numpy(images).to(dev)
         self.labels = torch.from_numpy(labels).to(dev)
+        self.lut = normalize_lut().to(dev)
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
         self.gen = torch.Generator().manual_seed(int(seed))
         self.rank, self.world = int(rank), int(world_size)  # data-parallel: every rank takes its stride of the epoch order
@@ -87,4 +95,6 @@ class STL10Loader:
         order = order[self.rank::self.world].to(self.images.device)
         for i in range(len(self)):
             idx = order[i * self.batch_size:(i + 1) * self.batch_size]
-            yield normalize_uint8(self.images.index_select(0, idx)), self.labels.index_select(0, idx)
+            u8 = self.images.index_select(0, idx)
+            x = self.lut.index_select(0, u8.reshape(-1).to(torch.int32)).view(u8.shape)
+            yield x, self.labels.index_select(0, idx)
