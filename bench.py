@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--sample-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-elided", action="store_true", help="skip the secondary dead-attention-elided leg")
     return ap.parse_args()
 
 
@@ -196,6 +197,32 @@ def main():
     value = imgs / dt
     final_loss = float(loss.item())
 
+    # ---------------- secondary leg (never the headline): the same steps with unet.ELIDE_DEAD_ATTENTION on.  With the
+    # one-token CLIP context the self-attention blocks and to_q / to_k cannot reach the output; skipping
+    # them leaves outputs and live gradients unchanged (tests/test_gpu_train_sample.py::test_elide_dead_attention_is_exact)
+    elided = None
+    if not a.no_elided:
+        from diffusion_model_amd import unet as U
+        U.ELIDE_DEAD_ATTENTION[0] = True
+        try:
+            for _ in range(2):
+                opt_step()
+            barrier()
+            t0e = time.perf_counter()
+            for _ in range(a.steps):
+                opt_step()
+            barrier()
+            dte = time.perf_counter() - t0e
+        finally:
+            U.ELIDE_DEAD_ATTENTION[0] = False
+        if world > 1:
+            tt = torch.tensor([dte], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dte = float(tt.item())
+        elided = {"value": imgs / dte, "unit": "img/s", "ms_per_step": dte / a.steps * 1e3,
+                  "what": "same config with the provably dead self-attention / to_q / to_k work skipped (opt-in, "
+                          "unet.ELIDE_DEAD_ATTENTION); identical outputs and live gradients; NOT the headline value"}
+
     # ---------------- sampling leg (batch-sharded, no collective in the loop)
     sampling = None
     if a.sample_images > 0:
@@ -219,6 +246,24 @@ def main():
                     "images": S * world, "steps": a.sample_steps, "seconds": ds, "guidance": 6.0, "eta": 1.0,
                     "cond_uncond_batched": True, "finite": ok,
                     "mfma_frac_algorithmic": (S * world / ds) * FWD_FLOP_PER_IMG * 2 * a.sample_steps / (PEAK_BF16 * world)}
+        if elided is not None:  # the same sampling run with the dead attention work skipped (secondary, see above)
+            from diffusion_model_amd import unet as U
+            U.ELIDE_DEAD_ATTENTION[0] = True
+            try:
+                smp.sample(z[:S], labels, 6.0, 1.0, num_time_steps=500, t_stop=497)
+                barrier()
+                t1 = time.perf_counter()
+                x0e = smp.sample(z, labels, 6.0, 1.0, num_time_steps=a.sample_steps)
+                barrier()
+                dse = time.perf_counter() - t1
+            finally:
+                U.ELIDE_DEAD_ATTENTION[0] = False
+            if world > 1:
+                tt = torch.tensor([dse], device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dse = float(tt.item())
+            elided["sampling_value"] = S * world / dse
+            elided["sampling_finite"] = bool(torch.isfinite(x0e).all().item())
 
     if rank != 0:
         if world > 1:
@@ -235,6 +280,8 @@ def main():
                    "parallelism": f"dp{world}", "weights": "reference init (seed 0), output_conv N(0,0.05^2)"},
         "step_mfma_frac_algorithmic": value * TRAIN_FLOP_PER_IMG / (PEAK_BF16 * world),
     }
+    if elided:
+        out["dead_attention_elided"] = elided
     if sampling:
         out["sampling"] = sampling
     if not a.no_roofline:

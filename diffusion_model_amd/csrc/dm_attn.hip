@@ -9,8 +9,11 @@
 // to the V^T operand instead, for free, through the row addresses of ds_read_b64_tr_b16.
 // The same trick (with q and key swapped) serves dV/dK, and again dQ.
 //
-// With head dims this small the kernels are VALU/exp-bound, not MFMA-bound (64 MFMA flop per
-// score element against ~12 VALU ops); see DESIGN.md.
+// With head dims this small the kernels are VALU-issue-bound, not MFMA-bound (64 MFMA flop per
+// score element); the flash kernels therefore push per-element work onto the MFMA pipe (see
+// "shared pieces of the flash kernels" below and DESIGN.md section 3).  Three kernel families by
+// key count: one context token (streaming kernels, the softmax is identically 1), 2..16 tokens
+// (VALU kernels), otherwise the flash kernels.
 //
 // Reference semantics replaced: F.scaled_dot_product_attention(q,k,v,dropout_p) with scale
 // 1/sqrt(hd), non-causal (unet.py:119-126,136,165-172,214) and its autograd backward.
@@ -792,7 +795,7 @@ __global__ void attn_small_finish_kernel(const AttnParams p, const float* __rest
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long bk = i / C;
-    p.dk[bk * p.lddk + c] = (bf16)ws[i];
+    if (p.dk) p.dk[bk * p.lddk + c] = (bf16)ws[i];
     p.dv[bk * p.lddv + c] = (bf16)ws[n + i];
   }
 }
@@ -812,12 +815,16 @@ __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
   const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
   const int sub = p.hd >> 3;  // threads per head: 1, 2 or 4
-  const bf16x8 kr = *reinterpret_cast<const bf16x8*>(p.k + (long)b * p.ldk + c8);
   const bf16x8 vr = *reinterpret_cast<const bf16x8*>(p.v + (long)b * p.ldv + c8);
   float kf[8];
   bf16x8 vs, vz;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { kf[j] = (float)kr[j] * p.scale; vs[j] = (bf16)((float)vr[j] * p.inv_keep); vz[j] = (bf16)0.f; }
+  for (int j = 0; j < 8; ++j) { kf[j] = 0.f; vs[j] = (bf16)((float)vr[j] * p.inv_keep); vz[j] = (bf16)0.f; }
+  if (p.lse) {  // q and k are only read for the log-sum-exp output (optional with one key: dm_hip.h)
+    const bf16x8 kr = *reinterpret_cast<const bf16x8*>(p.k + (long)b * p.ldk + c8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kf[j] = (float)kr[j] * p.scale;
+  }
   const bool drop = p.thresh != 0u;
   const int bh = b * p.H + h;
   for (int q = blockIdx.x * QPB + qs; q < p.Nq; q += gridDim.x * QPB) {
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += (float)d[j];
     }
-    *reinterpret_cast<bf16x8*>(p.dq + row * p.lddq + c8) = vz;
+    if (p.dq) *reinterpret_cast<bf16x8*>(p.dq + row * p.lddq + c8) = vz;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) sAcc[(qs * TPQ * 8) + (tid % TPQ) * 8 + j] = acc[j];
@@ -875,13 +882,17 @@ bool small_ok(const AttnParams& p) {
 }
 
 int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
-  DM_REQUIRE(a && a->q && a->k && a->v && a->o && a->lse);
+  DM_REQUIRE(a && a->v && a->o);
   DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32);
   DM_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
+  // With ONE key the output does not depend on q or k (softmax over one element), so a caller that has no use for
+  // the log-sum-exp may pass q = k = lse = NULL, and in backward dq = dk = NULL (both are identically zero).
+  const bool onekey_min = a->Nk == 1 && !a->lse && (!bwd || (!a->dq && !a->dk));
+  DM_REQUIRE(onekey_min || (a->q && a->k && a->lse));
   DM_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0);
   DM_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f);
   if (bwd) {
-    DM_REQUIRE(a->d_o && a->dq && a->dk && a->dv && a->delta);
+    DM_REQUIRE(a->d_o && a->dv && a->delta && (onekey_min || (a->dq && a->dk)));
     DM_REQUIRE(a->lddo % 8 == 0 && a->ldo % 8 == 0 && a->lddq % 4 == 0 && a->lddk % 4 == 0 && a->lddv % 4 == 0);
   }
   p.q = (const bf16*)a->q; p.ldq = a->ldq; p.k = (const bf16*)a->k; p.ldk = a->ldk;
@@ -907,6 +918,7 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   AttnParams p{};
   const int rc = fill(p, a, false);
   if (rc != DM_OK) return rc;
+  if (!p.q && !onekey_ok(p)) return DM_ERR_ARG;  // the q-less form exists only on the one-token path
   if (onekey_ok(p)) {
     const int QPB = 256 / ((p.H * p.hd) >> 3);
     int gx = (p.Nq + QPB - 1) / QPB;
@@ -942,6 +954,7 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   const int rc = fill(p, a, true);
   if (rc != DM_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (!p.q && !onekey_ok(p)) return DM_ERR_ARG;  // the q-less form exists only on the one-token path
   if (onekey_ok(p)) {
     const int C = p.H * p.hd, QPB = 256 / (C >> 3);
     float* ws = p.delta;  // fp32 [2][B,1,C] reduction scratch (the caller sizes it: dm_hip.h)

@@ -320,6 +320,37 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     return dq, dk, dv
 
 
+def attn_onekey_fwd(v, Nq, heads, *, drop_p=0.0, drop_seed=0):
+    """One context token, no log-sum-exp wanted: o[b, q] = dropout(v[b, 0]) for every query (the q-less form of
+    dm_attn_fwd, include/dm_hip.h).  v: [B,1,C] -> o [B,Nq,C]."""
+    B, Nk, Cc = v.shape
+    assert Nk == 1
+    o = torch.empty((B, Nq, Cc), dtype=BF16, device=v.device)
+    a = AttnArgs()
+    a.v, a.ldv, a.o, a.ldo = _p(v), _act(v, "v"), _p(o), Cc
+    a.B, a.heads, a.Nq, a.Nk, a.hd = B, heads, Nq, 1, Cc // heads
+    a.scale = 1.0 / ((Cc // heads) ** 0.5)
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    check(_lib.lib().dm_attn_fwd(C.byref(a), _stream()), "dm_attn_fwd")
+    return o
+
+
+def attn_onekey_bwd(v, o, d_o, heads, *, drop_p=0.0, drop_seed=0):
+    """Backward of attn_onekey_fwd: dv [B,1,C] = sum_q dropout-mask * dO (dq and dk are identically zero)."""
+    B, Nk, Cc = v.shape
+    Nq = o.shape[1]
+    dv = torch.empty((B, 1, Cc), dtype=BF16, device=v.device)
+    delta = torch.empty(2 * B * Cc, dtype=torch.float32, device=v.device)
+    a = AttnArgs()
+    a.v, a.ldv, a.o, a.ldo = _p(v), _act(v, "v"), _p(o), _act(o, "o")
+    a.d_o, a.lddo, a.dv, a.lddv, a.delta = _p(d_o), _act(d_o, "d_o"), _p(dv), Cc, _p(delta)
+    a.B, a.heads, a.Nq, a.Nk, a.hd = B, heads, Nq, 1, Cc // heads
+    a.scale = 1.0 / ((Cc // heads) ** 0.5)
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    check(_lib.lib().dm_attn_bwd(C.byref(a), _stream()), "dm_attn_bwd")
+    return dv
+
+
 # --------------------------------------------------------------------------- layout / elementwise
 def nchw_to_nhwc(x: torch.Tensor, cpad: int = 0, out=None) -> torch.Tensor:
     B, Cc, H, W = x.shape

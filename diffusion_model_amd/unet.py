@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -354,9 +355,17 @@ class CrossAttention(HipModule):
         self.to_out = nn.Linear(query_dim, query_dim, bias=False)
 
     # ctx: bf16 [B, L, Dc]
-    def _fwd(self, x, ctx, res=None, out=None):
+    def _fwd(self, x, ctx, res=None, out=None, elide=False):
         B, H, W, C = x.shape
         N = H * W
+        if elide:  # one context token: the output does not depend on x (see ELIDE_DEAD_ATTENTION)
+            vc = K.gemm(ctx, PW.of(self.to_v).fwd, C)
+            p = self.dropout_prob if self.training else 0.0
+            seed = next(_SEED) if p > 0 else 0
+            o = K.attn_onekey_fwd(vc, N, self.num_heads, drop_p=p, drop_seed=seed)
+            y = K.gemm(o, PW.of(self.to_out).fwd, C, res=None if res is None else res.view(B, N, C),
+                       out=None if out is None else out.view(B, N, C))
+            return y.view(B, H, W, C), (None, ctx, None, None, vc, o, None, p, seed)
         tok = x.view(B, N, C)
         q = K.gemm(tok, PW.of(self.to_q).fwd, C)
         kc = K.gemm(ctx, PW.of(self.to_k).fwd, C)
@@ -370,10 +379,15 @@ class CrossAttention(HipModule):
 
     def _bwd(self, dy, saved, g: Grads, add=None, need_dctx=False):
         tok, ctx, q, kc, vc, o, lse, p, seed = saved
-        B, N, C = tok.shape
+        B, N, C = o.shape
         dyt = dy.view(B, N, C)
         d_o = K.gemm(dyt, PW.of(self.to_out).bwd, C)
         K.wgrad_side(o, dyt, g.of(self.to_out.weight), None, taps=1)
+        if tok is None:  # elided form: dq = dk = 0 exactly, so to_q / to_k get no gradient and dx is just `add`
+            dv = K.attn_onekey_bwd(vc, o, d_o, self.num_heads, drop_p=p, drop_seed=seed)
+            K.wgrad_side(ctx, dv, g.of(self.to_v.weight), None, taps=1)
+            g.of(self.to_q.weight), g.of(self.to_k.weight)  # (allocate the zero gradients for autograd callers)
+            return add, None
         dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
         K.wgrad_side(tok, dq, g.of(self.to_q.weight), None, taps=1)
         K.wgrad_side(ctx, dk, g.of(self.to_k.weight), None, taps=1)
@@ -459,6 +473,14 @@ class Downsample(HipModule):
         return (K.nhwc_to_nchw(self._bwd(_nhwc_in(dout), saved, g)),)
 
 
+# With ONE context token the cross-attention softmax is identically 1, so its output does not depend on its query
+# input: in `x = attention(x); x = cross_attention(x, ctx); x = x + res` (unet.py:269-276) the self-attention block
+# and the to_q / to_k projections cannot influence the output, and their gradients are exactly zero.
+# ELIDE_DEAD_ATTENTION[0] = True skips that provably dead work (outputs, live gradients and the dropout seed
+# sequence are unchanged bit for bit).  Off by default: the default network runs everything the reference runs.
+ELIDE_DEAD_ATTENTION = [os.environ.get("DM_ELIDE_DEAD_ATTENTION", "0") == "1"]
+
+
 class UnetLayer(HipModule):
     """Reference unet.py:239-285."""
 
@@ -489,7 +511,12 @@ class UnetLayer(HipModule):
         r, s_res = self.res_block._fwd(x, temb)
         dst = None if up else skip_out
         s_a = s_c = None
-        if has_a and has_c:
+        elide = has_c and ELIDE_DEAD_ATTENTION[0] and ctx.shape[1] == 1
+        if elide:
+            if has_a and self.attention.training and self.attention.dropout_prob > 0:
+                next(_SEED)  # keep the dropout seed sequence of the un-elided network
+            xo, s_c = self.cross_attention._fwd(r, ctx, res=r, out=dst, elide=True)
+        elif has_a and has_c:
             xa, s_a = self.attention._fwd(r)
             xo, s_c = self.cross_attention._fwd(xa, ctx, res=r, out=dst)
         elif has_a:
@@ -519,7 +546,12 @@ class UnetLayer(HipModule):
         else:
             dxo = self.downsample._bwd(dy, s_ud, g, add=d_skip)
         # xo = attn_path(r) + r
-        if s_a is not None and s_c is not None:
+        if s_c is not None and s_c[0] is None:  # elided: the attention path carries no gradient back to r
+            self.cross_attention._bwd(dxo, s_c, g)
+            if hasattr(self, "attention"):  # zero gradients, exactly: leave the accumulators untouched
+                g.of(self.attention.linear_qkv.weight), g.of(self.attention.linear_out.weight)
+            dr = dxo  # d(xo)/d(r) is the residual branch alone
+        elif s_a is not None and s_c is not None:
             dxa, _ = self.cross_attention._bwd(dxo, s_c, g)
             dr = self.attention._bwd(dxa, s_a, g, add=dxo)
         elif s_a is not None:

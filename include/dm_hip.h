@@ -147,7 +147,10 @@ typedef struct dm_attn_args {
 } dm_attn_args;
 /* Flash-style fused softmax(QK^T*scale)V on bf16 MFMA, online softmax, no N x N matrix in
  * memory.  Replaces F.scaled_dot_product_attention for self- and cross-attention
- * (unet.py:119-126,136,165-172,214). */
+ * (unet.py:119-126,136,165-172,214).
+ * One key (Nk == 1, the CLIP context of unet.py:205-214): the softmax is identically 1, so o = dropout(v), dq = dk = 0 and
+ * lse = scale * q.k exactly; a caller with no use for lse may pass q = k = lse = NULL (forward) and additionally
+ * dq = dk = NULL (backward: only dv is produced).  Any other NULL is DM_ERR_ARG. */
 int dm_attn_fwd(const dm_attn_args* args, dm_stream_t stream);
 int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
 

@@ -311,3 +311,54 @@ def test_mnist_train_loop_runs():
                               log=logs.append)
     assert tr.opt_step == 6 and len(logs) == 2 and all("Loss" in s for s in logs)
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+# --------------------------------------------------------------------------- opt-in dead-attention elision
+def test_elide_dead_attention_is_exact():
+    """unet.ELIDE_DEAD_ATTENTION: with ONE context token the self-attention block and to_q / to_k cannot reach the
+    output.  Skipping them must leave the output and dL/dx bit-identical (train mode, dropout on, same
+    seed sequence), the live parameter gradients equal up to the summation-order noise of the split-K atomics, and
+    the dead parameters' gradients exactly zero; a multi-token context must not be touched by the switch."""
+    import itertools
+    from diffusion_model_amd import unet as U
+    torch.manual_seed(0)
+    m = U.UNET(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.1)
+    with torch.no_grad():
+        m.output_conv.weight.normal_(0, 0.05)
+    m = m.to(dev())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, 32, 32, generator=g).to(dev())
+    t = torch.tensor([5, 400])
+
+    def run(ctx, elide):
+        U.ELIDE_DEAD_ATTENTION[0] = elide
+        U._SEED = itertools.count(1000)  # the same dropout seed sequence in every run
+        m.train()
+        m.zero_grad()
+        xg = x.clone().requires_grad_()
+        y = m(xg, t, ctx)
+        y.square().mean().backward()
+        return y.detach().clone(), xg.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        ctx1 = torch.nn.functional.normalize(torch.randn(2, 512, generator=g), dim=-1).to(dev())
+        y0, dx0, g0 = run(ctx1, False)
+        y1, dx1, g1 = run(ctx1, True)
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        gmax = max(float(v.abs().max()) for v in g0.values())
+        n_dead = 0
+        for n, a in g0.items():
+            b = g1.get(n, torch.zeros_like(a))
+            if ".attention.linear" in n or "to_q" in n or "to_k" in n:
+                n_dead += 1
+                assert float(b.abs().max()) == 0.0, n
+                assert float(a.abs().max()) <= 1e-6 * gmax, f"{n}: the un-elided gradient is not dead"
+            else:
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, n
+        assert n_dead >= 2 * 2 + 2 * 4  # two self-attention blocks, to_q/to_k of the four cross-attention blocks
+        ctx4 = torch.nn.functional.normalize(torch.randn(2, 4, 512, generator=g), dim=-1).to(dev())
+        ya, dxa, _ = run(ctx4, False)
+        yb, dxb, _ = run(ctx4, True)     # L = 4: nothing is dead, nothing may be skipped
+        assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    finally:
+        U.ELIDE_DEAD_ATTENTION[0] = False
