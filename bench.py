@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--sample-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-elided", action="store_true", help="skip the secondary dead-attention-elided leg")
+    ap.add_argument("--no-elided", action="store_true", help="skip the secondary legs (dropout 0, dead-attention elided)")
     return ap.parse_args()
 
 
@@ -197,6 +197,33 @@ def main():
     value = imgs / dt
     final_loss = float(loss.item())
 
+    # ---------------- secondary leg: dropout 0.0 ("parity mode", SURVEY 8d asks for both); the headline keeps 0.1
+    dropout0 = None
+    if not a.no_elided and a.dropout > 0:
+        saved_p = []
+        for mod in model.modules():
+            for attr in ("p", "dropout_prob"):
+                if isinstance(getattr(mod, attr, None), float):
+                    saved_p.append((mod, attr, getattr(mod, attr)))
+                    setattr(mod, attr, 0.0)
+        try:
+            for _ in range(2):
+                opt_step()
+            barrier()
+            t0d = time.perf_counter()
+            for _ in range(a.steps):
+                opt_step()
+            barrier()
+            dtd = time.perf_counter() - t0d
+        finally:
+            for mod, attr, val in saved_p:
+                setattr(mod, attr, val)
+        if world > 1:
+            tt = torch.tensor([dtd], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtd = float(tt.item())
+        dropout0 = {"value": imgs / dtd, "unit": "img/s", "ms_per_step": dtd / a.steps * 1e3}
+
     # ---------------- secondary leg (never the headline): the same steps with unet.ELIDE_DEAD_ATTENTION on.  With the
     # one-token CLIP context the self-attention blocks and to_q / to_k cannot reach the output; skipping
     # them leaves outputs and live gradients unchanged (tests/test_gpu_train_sample.py::test_elide_dead_attention_is_exact)
@@ -280,6 +307,8 @@ def main():
                    "parallelism": f"dp{world}", "weights": "reference init (seed 0), output_conv N(0,0.05^2)"},
         "step_mfma_frac_algorithmic": value * TRAIN_FLOP_PER_IMG / (PEAK_BF16 * world),
     }
+    if dropout0:
+        out["train_dropout_0"] = dropout0
     if elided:
         out["dead_attention_elided"] = elided
     if sampling:
