@@ -85,10 +85,12 @@ class CFGSampler:
     @torch.no_grad()
     def sample(self, z: torch.Tensor, labels: torch.Tensor, guidance_scale=6.0, eta: float = 1.0,
                num_time_steps: Optional[int] = None, generator: Optional[torch.Generator] = None,
-               noises=None, t_stop: int = 0) -> torch.Tensor:
+               noises=None, t_stop: int = 0, snapshots: Optional[dict] = None) -> torch.Tensor:
         """z: [S,C,H,W] fp32 start noise; labels: [S] long.  Guidance is 0.0 for samples whose label is the
         unconditional id (reference visualization.py:424).  ``noises[t]`` overrides the RNG (tests);
-        ``t_stop>0`` stops after step t_stop (bounded timing runs) and returns the un-clamped latent."""
+        ``t_stop>0`` stops after step t_stop (bounded timing runs) and returns the un-clamped latent.
+        ``snapshots``: a dict whose keys are the timesteps to capture (visualization.py:144-146); it is filled
+        with the clamped latent after those steps (key 0 = the final image)."""
         from . import kernels as K
         model = self.model
         model.eval()
@@ -124,4 +126,45 @@ class CFGSampler:
             else:
                 noise = z  # unused (coef[4] == 0)
             z = K.cfg_ddpm_step(z, v[:S], v[S:], noise, coefs[i])
+            if snapshots is not None and t in snapshots:
+                snapshots[t] = torch.clamp(z, -1, 1)
         return z
+
+    @torch.no_grad()
+    def sample_from(self, x_t: torch.Tensor, labels: torch.Tensor, t_start, guidance_scale=0.0, eta: float = 1.0,
+                    generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Partial reverse process (reference visualization.py:264-330, 333-401: the reconstruction panels):
+        sample i starts at timestep ``t_start[i]`` from the already-noised ``x_t[i]`` and walks t_start[i]..0.
+        All samples run as ONE batch: they are ordered by start time and join the UNet batch when the global
+        timestep reaches their own, so a sweep over several start times costs max(t_start)+1 forwards, not the
+        sum.  Returns the clamped x0 estimates in the caller's order."""
+        from . import kernels as K
+        model = self.model
+        model.eval()
+        S, dev = x_t.shape[0], x_t.device
+        starts = [int(t) for t in (t_start.tolist() if torch.is_tensor(t_start) else t_start)]
+        assert len(starts) == S and min(starts) >= 0 and max(starts) < self.sched.T
+        order = sorted(range(S), key=lambda i: -starts[i])
+        inv = torch.empty(S, dtype=torch.long)
+        inv[torch.tensor(order)] = torch.arange(S)
+        oi = torch.tensor(order, device=dev)
+        z = x_t.contiguous().index_select(0, oi).clone()
+        labels = labels.to(dev).long().index_select(0, oi)
+        starts = [starts[i] for i in order]
+        g = torch.full((S,), float(guidance_scale), dtype=torch.float32)
+        g[labels.cpu() == self.uncond_id] = 0.0
+        beta, abar = self.sched.beta_cpu, self.sched.alpha_bar_cpu
+        table = self.table.to(dev)
+        ctx_u, ctx_c = table[torch.full_like(labels, self.uncond_id)], table[labels]
+        for t in range(starts[0], -1, -1):
+            n = sum(1 for s0 in starts if s0 >= t)          # the active samples are a prefix
+            zz = torch.cat([z[:n], z[:n]])
+            tt = torch.full((2 * n,), t, dtype=torch.long, device=dev)
+            v, _ = model._fwd(zz, tt, torch.cat([ctx_u[:n], ctx_c[:n]]).contiguous())
+            coef = step_coefficients(beta, abar, t, g[:n], eta, n, final=(t == 0)).to(dev)
+            if t > 1 and eta > 0.0:
+                noise = torch.randn(z[:n].shape, dtype=torch.float32, device=dev, generator=generator)
+            else:
+                noise = zz[:n]  # unused (coef[4] == 0)
+            z[:n] = K.cfg_ddpm_step(z[:n].contiguous(), v[:n], v[n:], noise, coef)
+        return z.index_select(0, inv.to(dev))

@@ -362,3 +362,48 @@ def test_elide_dead_attention_is_exact():
         assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
     finally:
         U.ELIDE_DEAD_ATTENTION[0] = False
+
+
+# --------------------------------------------------------------------------- monitoring images (visualization.py)
+def test_visualization_batched_jobs(tmp_path):
+    """Drop-ins for the reference's monitoring functions: the batched partial reverse process
+    (all start times of a reconstruction sweep in one batch) against the reference's serial per-start walk with the
+    callback contract, and the PNG outputs at the reference's paths."""
+    from PIL import Image
+    from diffusion_model_amd import utils, visualization as V
+    model, _ = make_model(seed=4)
+    model.eval()
+    T = 8
+    sched = utils.DDPM_beta_t_cosine_scheduler(T)
+    utils._load_clip_context_table()
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.clamp(torch.randn(1, 3, 32, 32, generator=g) * 0.5, -1, 1).to(d)
+    labels = torch.tensor([4], device=d)
+    slow_fn = lambda *a: utils._cfg_predict_eps_from_v(*a)  # noqa: E731  (not the package's own object: serial path)
+    torch.manual_seed(11)
+    t0s, x_ts, fast = V._reconstruct(model, sched, x, labels, [6, 3, 5], 6.0, 0.0, utils._cfg_predict_eps_from_v, T)
+    torch.manual_seed(11)
+    t0s2, x_ts2, slow = V._reconstruct(model, sched, x, labels, [6, 3, 5], 6.0, 0.0, slow_fn, T)
+    assert t0s == t0s2 == [6, 3, 5]
+    for a, b, xa, xb in zip(fast, slow, x_ts, x_ts2):
+        assert torch.equal(xa, xb)                       # same noised starts
+        assert tuple(a.shape) == (1, 3, 32, 32) and float(a.abs().max()) <= 1.0
+        assert_close(a, b, 3e-2, "batched vs serial reconstruction")
+    # the PNG writers, at the reference's paths (96x96 start noise as in the reference's sample_noise)
+    out = str(tmp_path)
+    V.generate_denoise_collage(model, sched, 3, 17, [5, 2, 0], d, T, 1.0, utils._cfg_predict_eps_from_v, out,
+                               labels=labels, guidance_scale=6.0)
+    V.generate_random_sample_image(model, sched, 3, d, T, 1.0, None, out, labels=labels, guidance_scale=6.0)
+    ds = [(x[0].cpu(), 4)]
+    V.reconstruct_from_dataset_sample(model, sched, ds, 3, d, T, 1.0, None, out, t_start=4, guidance_scale=6.0)
+    V.reconstruct_sweep(model, sched, [(x.cpu(), torch.tensor([4]))], 3, d, T, 1.0, None, out, t_list=[6, 3])
+    e = tmp_path / "epoch_3"
+    names = {"epoch_3_step_17_stl10_collage.png": 3, "epoch_3_stl10_sample.png": 1,
+             "epoch_3_reconstruction_t4.png": 3, "epoch_3_reconstruction_sweep.png": 3}
+    for n, panels in names.items():
+        im = Image.open(e / n)
+        assert im.width > panels * 60 and im.height > 40, (n, im.size)
+        import numpy as np
+        a = torch.from_numpy(np.asarray(im.convert("L"), dtype=np.float32))
+        assert float(a.std()) > 1.0  # not a blank sheet
