@@ -63,8 +63,11 @@ def _checkpoint_dict(model, trainer: Trainer, ema: ModelEmaV2) -> dict:
 def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train_loader: Optional[Iterable] = None,
           total_epochs: int = TOTAL_EPOCHS_NEW, start_epoch: int = START_EPOCH, checkpoint_dir: str = ".",
           checkpoint_every: int = 5, on_epoch_end: Optional[Callable] = None, check_finite: bool = True,
-          distributed: Optional[bool] = None, log: Callable = print):
-    """Reference main_stl10.py:352-545.  Returns ``(model, ema, trainer)``."""
+          distributed: Optional[bool] = None, log: Callable = print, monitor_dir: Optional[str] = None,
+          monitor_every: int = 1):
+    """Reference main_stl10.py:352-545.  Returns ``(model, ema, trainer)``.  ``monitor_dir``: when given, the
+    reference's end-of-epoch images (:521-524: reconstruction sweep, denoising collage, fixed-seed class grid) are
+    written under it every ``monitor_every`` epochs from the EMA weights, each as one batched sampling job."""
     scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
     if train_loader is None:
         try:  # reference: torchvision STL10(root='stl10_data', split='train'), shuffled, batch_size BATCH_SIZE
@@ -123,6 +126,15 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
             loss = trainer.micro_step(x, context, t, e, step_now=do_step, check_finite=check_finite)
             sum_loss += loss.detach().reshape(-1)[:1]
         log(f"Epoch {epoch + 1} | Loss {float(sum_loss.item()) / max(1, n_batches):.5f}")
+        if monitor_dir is not None and (epoch + 1) % max(1, monitor_every) == 0 and utils.CONTEXT_TABLE is not None:
+            from . import visualization as V
+            V.reconstruct_sweep(ema.module, scheduler, train_loader, epoch + 1, device, NUM_TIME_STEPS, SAMPLING_ETA,
+                                None, monitor_dir, t_list=[700, 500, 300, 200], guidance_scale=CFG_SCALE)
+            V.generate_denoise_collage(ema.module, scheduler, epoch + 1, 1, [499, 400, 300, 200, 100, 50, 15, 0], device,
+                                       NUM_TIME_STEPS, SAMPLING_ETA, None, monitor_dir, guidance_scale=CFG_SCALE)
+            grid = generate_fixed_seed_class_grid(ema.module, scheduler, num_time_steps=NUM_TIME_STEPS)
+            V.save_image_strip([g for g in grid], [V.STL10_CLASS_NAMES[i] for i in range(grid.shape[0])],
+                               os.path.join(monitor_dir, f"epoch_{epoch + 1}", f"epoch_{epoch + 1}_fixed_seed_grid.png"))
         if on_epoch_end is not None:
             on_epoch_end(epoch + 1, model, ema, scheduler)
         if checkpoint_every and (epoch + 1) % checkpoint_every == 0:

@@ -233,9 +233,16 @@ def test_train_from_stl10_binary_files(tmp_path):
     x0, y0 = next(iter(loader))
     assert x0.is_cuda and torch.equal(x0.cpu(), normalize_uint8(torch.from_numpy(imgs[:4])))
     logs = []
-    model, ema, tr = M.train(None, train_loader=loader, total_epochs=21, start_epoch=20, checkpoint_every=0,
-                             log=logs.append)
+    old_T = M.NUM_TIME_STEPS
+    M.NUM_TIME_STEPS = 8   # keeps the end-of-epoch monitoring jobs (three reverse processes) short
+    try:
+        model, ema, tr = M.train(None, train_loader=loader, total_epochs=21, start_epoch=20, checkpoint_every=0,
+                                 log=logs.append, monitor_dir=str(tmp_path / "mon"))
+    finally:
+        M.NUM_TIME_STEPS = old_T
     assert tr.opt_step == 2                                    # 3 batches, accumulation 2: steps after batch 2 and 3
+    made = sorted(p.name for p in (tmp_path / "mon" / "epoch_21").iterdir())
+    assert made == ["epoch_21_fixed_seed_grid.png", "epoch_21_reconstruction_sweep.png", "epoch_21_step_1_stl10_collage.png"]
     line = [s for s in logs if s.startswith("Epoch 21 | Loss")][0]
     assert math.isfinite(float(line.split("Loss")[1]))
 
