@@ -48,7 +48,7 @@ struct ConvParams {
 
 // Epilogue shared by the conv and the streaming GEMM kernels: lane holds couts [cq..cq+3] of pixel
 // (lane & 15) of each of its wave's m-tiles.
-template <int MT, int NT, int TW, int MODE>
+template <int MT, int NT, int TW, int MODE, bool WIDE_ONLY = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MT][NT], int nb, int wave, int lane,
                                               int b, int h0, int w0, long m0) {
   const int cq = (lane >> 4) * 4;
@@ -121,11 +121,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           if (ok) {
             *reinterpret_cast<u32x4*>(p.y + pix * p.ldy + co8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
           }
+          // streaming GEMM: one column pair at a time (the scheduler otherwise batches all pairs' addresses, residual
+          // loads and packs up front: ~60 VGPRs that cost the HBM-bound kernel a resident wave per SIMD)
+          if constexpr (MODE == MODE_GEMM) __builtin_amdgcn_sched_barrier(0);
         }
       }
       return;
     }
   }
+  if constexpr (WIDE_ONLY) return;  // the caller checked the wide path's conditions on the host
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co = (nb * NT + nt) * 16 + cq;
@@ -419,8 +423,8 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
 //     fragments straight from global memory in MFMA operand layout (16 rows x 64 B per load; the two
 //     halves of a 128-byte line are fetched by consecutive loads), one whole tile ahead of the MFMAs;
 //   * the epilogue (bias / time-embedding / residual / fp32 out) is the conv kernel's.
-template <int MT, int NT, int NKS>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p, const int ntiles) {
+template <int MT, int NT, int NKS, bool WIDE>
+__global__ __launch_bounds__(256, (WIDE && MT == 1 && NKS <= 4) ? 3 : 2) void gemm_stream_kernel(const ConvParams p, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char sW[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.y;
@@ -469,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p,
   __syncthreads();
 
   auto work = [&](int t, bf16x8(&xa)[MT][NKS], bf16x8(&xn)[MT][NKS]) {
+    asm volatile("" ::: "memory");  // keep the epilogue's per-column loads (bias) inside the tile loop: hoisted, they cost 32+ VGPRs
     if (t + nwaves < ntiles) load_x(t + nwaves, xn);
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p,
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the weight fragments of later k-steps out of registers
     }
-    conv_epilogue<MT, NT, 16, MODE_GEMM>(p, acc, nb, 0, lane, 0, 0, 0, (long)t * MT * 16);
+    conv_epilogue<MT, NT, 16, MODE_GEMM, WIDE>(p, acc, nb, 0, lane, 0, 0, 0, (long)t * MT * 16);
   };
   for (; tile < ntiles; tile += 2 * nwaves) {
     work(tile, xa0, xa1);
@@ -502,11 +507,11 @@ __global__ __launch_bounds__(256, 2) void gemm_stream_kernel(const ConvParams p,
   }
 }
 
-template <int MT, int NT, int NKS>
-int launch_gemm_stream(const ConvParams& p, hipStream_t st) {
+template <int MT, int NT, int NKS, bool WIDE>
+int launch_gemm_stream_v(const ConvParams& p, hipStream_t st) {
   constexpr int LDS = NKS * NT * 1024;
   static_assert(LDS <= 64 * 1024, "two workgroups per CU");
-  auto k = gemm_stream_kernel<MT, NT, NKS>;
+  auto k = gemm_stream_kernel<MT, NT, NKS, WIDE>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -521,6 +526,15 @@ int launch_gemm_stream(const ConvParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), LDS, st, p, ntiles);
   DM_LAUNCH_CHECK();
   return DM_OK;
+}
+
+// The variant whose epilogue holds only the 16-byte-store path (bf16 output, whole channel tiles, aligned rows) needs
+// ~30 fewer VGPRs: a third resident wave per SIMD for this HBM-bound kernel.  Same conditions as conv_epilogue's.
+template <int MT, int NT, int NKS>
+int launch_gemm_stream(const ConvParams& p, hipStream_t st) {
+  const bool wide = (NT % 2 == 0) && p.y && !p.yf && !p.pool2 && p.n_valid == p.Cout && (p.ldy & 7) == 0 &&
+                    (reinterpret_cast<unsigned long long>(p.y) & 15) == 0;
+  return wide ? launch_gemm_stream_v<MT, NT, NKS, true>(p, st) : launch_gemm_stream_v<MT, NT, NKS, false>(p, st);
 }
 
 template <int NT>
