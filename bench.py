@@ -273,6 +273,25 @@ def main():
                     "images": S * world, "steps": a.sample_steps, "seconds": ds, "guidance": 6.0, "eta": 1.0,
                     "cond_uncond_batched": True, "finite": ok,
                     "mfma_frac_algorithmic": (S * world / ds) * FWD_FLOP_PER_IMG * 2 * a.sample_steps / (PEAK_BF16 * world)}
+        # DPM-Solver++(2M) leg (reference main_stl10.py:634-703, its default 50 steps): the same
+        # images on the fused multistep kernel.  Secondary: fewer UNet evaluations per image, not a faster kernel.
+        from diffusion_model_amd.dpm_solver import DPMSolverMultistepScheduler
+        dpm = DPMSolverMultistepScheduler(num_train_timesteps=500, beta_start=0.00085, beta_end=0.012,
+                                          beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                          algorithm_type="dpmsolver++", solver_order=2)
+        gd = torch.where(labels == 10, 0.0, 6.0)
+        smp.sample_dpm(z[:S], labels, dpm, cfg_scale=gd, num_inference_steps=3)
+        barrier()
+        t1 = time.perf_counter()
+        xd = smp.sample_dpm(z, labels, dpm, cfg_scale=gd, num_inference_steps=50)
+        barrier()
+        dd = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dd], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dd = float(tt.item())
+        sampling["dpm_solver_pp_2m"] = {"value": S * world / dd, "unit": "img/s", "steps": 50, "seconds": dd,
+                                        "guidance": 6.0, "finite": bool(torch.isfinite(xd).all().item())}
         if elided is not None:  # the same sampling run with the dead attention work skipped (secondary, see above)
             from diffusion_model_amd import unet as U
             U.ELIDE_DEAD_ATTENTION[0] = True

@@ -86,6 +86,8 @@ _SIGS = {
                                     c_void_p, c_long, c_void_p]),
     "dm_cfg_ddpm_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
                                  c_void_p]),
+    "dm_cfg_dpmpp2m_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
+                                    c_void_p]),
     "dm_sqnorm_workspace_bytes": (c_long, []),
     "dm_grad_norm_clipcoef": (c_int, [c_void_p, c_long, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_adamw_ema_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float,

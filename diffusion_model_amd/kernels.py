@@ -454,6 +454,20 @@ def cfg_ddpm_step(z, v_u, v_c, noise, coef, out=None):
     return out
 
 
+def cfg_dpmpp2m_step(z, v_u, v_c, x0_prev, coef, out=None, x0_out=None):
+    """One DPM-Solver++(2M) step; returns (z', x0).  ``x0_prev`` is read only by rows whose second-order flag is set."""
+    B = z.shape[0]
+    chw = z.numel() // B
+    if out is None:
+        out = torch.empty_like(z)
+    if x0_out is None:
+        x0_out = torch.empty_like(z)
+    check(_lib.lib().dm_cfg_dpmpp2m_step(_p(_f32(z, "z")), _p(_f32(v_u, "v_u")), _p(_f32(v_c, "v_c")),
+                                         _p(_f32(x0_prev, "x0_prev")), _p(_f32(coef, "coef")), _p(out), _p(x0_out), B,
+                                         chw, _stream()), "dm_cfg_dpmpp2m_step")
+    return out, x0_out
+
+
 def grad_norm_clipcoef(g, max_norm, pre_scale=1.0, out=None):
     L = _lib.lib()
     ws = workspace(L.dm_sqnorm_workspace_bytes(), g.device)

@@ -12,7 +12,7 @@ monitoring hooks can be attached through ``on_epoch_end``."""
 from __future__ import annotations
 
 import os
-from typing import Callable, Iterable, Optional
+from typing import Callable, Iterable, List, Optional
 
 import torch
 
@@ -173,3 +173,31 @@ def inference(checkpoint_path, label: Optional[int] = None, guidance_scale: floa
     ids = None if label is None else [int(label)]
     return generate_fixed_seed_class_grid(ema.module, scheduler, cfg_scale=guidance_scale, eta=SAMPLING_ETA,
                                           label_ids=ids, num_time_steps=num_time_steps, size=size)
+
+
+def generate_cfg_grids_dpm_solver(checkpoint_path: str, cfg_scales: Optional[List[float]] = None,
+                                  num_inference_steps: int = 50, clip_table_path: str = CLIP_TABLE_PATH, *,
+                                  output_dir: str = os.path.join("intermiate imagees", "dpm"),
+                                  latent_shape: tuple = (1, 3, 96, 96)):
+    """Reference main_stl10.py:634-703: load a checkpoint and write one fixed-seed class grid per CFG scale, sampled
+    with DPM-Solver++(2M) under the scheduler configuration the reference constructs (:676-684).  Each grid is one
+    batched job on the fused sampler.  Returns the list of latent batches (one per scale)."""
+    from . import visualization as V
+    from .dpm_solver import DPMSolverMultistepScheduler
+    if cfg_scales is None:
+        cfg_scales = [3.0, 5.0, 7.0]
+    model, ema = utils.load_checkpoint(checkpoint_path, clip_table_path)
+    scheduler = DPMSolverMultistepScheduler(num_train_timesteps=NUM_TIME_STEPS, beta_start=0.00085, beta_end=0.012,
+                                            beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                            algorithm_type="dpmsolver++", solver_order=2)
+    import re
+    m = re.search(r"epoch_(\d+)", os.path.basename(str(checkpoint_path)))    # main_stl10.py:567-580; 0 when absent
+    epoch = int(m.group(1)) if m else 0
+    outs = []
+    for cfg in cfg_scales:
+        outs.append(V.generate_fixed_seed_class_grid_dpm(ema.module, scheduler, epoch, 1, cfg_scale=cfg,
+                                                         num_inference_steps=num_inference_steps,
+                                                         label_ids=list(V.STL10_CLASS_NAMES.keys()),
+                                                         label_names=V.STL10_CLASS_NAMES, base_seed=42, device=device,
+                                                         output_dir=output_dir, latent_shape=latent_shape))
+    return outs

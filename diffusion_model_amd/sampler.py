@@ -15,8 +15,8 @@ def step_coefficients(beta: torch.Tensor, abar: torch.Tensor, t: int, guidance, 
                       final: bool = False) -> torch.Tensor:
     """[batch, 8] fp32 rows {sqrt(1-abar_t), sqrt(abar_t), 1/sqrt(alpha_t), beta_t/sqrt(1-abar_t),
     eta*sqrt(posterior_var) or 0, guidance, clamp flag, 0}.  `beta`/`abar` are the fp32 CPU tables;
-    `guidance` is a float or a per-sample [batch] tensor (0.0 for the unconditional label,
-    visualization.py:424)."""
+    `guidance` and `eta` are floats or per-sample [batch] tensors (guidance 0.0 for the
+    unconditional label, visualization.py:424)."""
     beta, abar = beta.detach().cpu(), abar.detach().cpu()
     abar_t, beta_t = abar[t], beta[t]
     alpha_t = 1.0 - beta_t
@@ -24,13 +24,15 @@ def step_coefficients(beta: torch.Tensor, abar: torch.Tensor, t: int, guidance, 
     sa = torch.sqrt(abar_t)
     ria = 1.0 / torch.sqrt(alpha_t)
     bs = beta_t / torch.sqrt(1.0 - abar_t)
-    ns = torch.tensor(0.0)
-    if (not final) and t > 1 and eta > 0.0:
+    eta = torch.as_tensor(eta, dtype=torch.float32)   # a float, or one eta per sample (inference_sweeps.py:127-133)
+    ns = torch.zeros(())
+    if (not final) and t > 1 and bool((eta > 0.0).any()):
         abar_prev = abar[t - 1]
         ns = eta * torch.sqrt(beta_t * (1.0 - abar_prev) / (1.0 - abar_t))
-    row = torch.stack([sig, sa, ria, bs, ns.float(), torch.tensor(0.0), torch.tensor(1.0 if final else 0.0),
+    row = torch.stack([sig, sa, ria, bs, torch.tensor(0.0), torch.tensor(0.0), torch.tensor(1.0 if final else 0.0),
                        torch.tensor(0.0)]).float()
     coef = row[None, :].repeat(batch, 1)
+    coef[:, 4] = ns.float()
     coef[:, 5] = torch.as_tensor(guidance, dtype=torch.float32)
     return coef.contiguous()
 
@@ -86,8 +88,8 @@ class CFGSampler:
     def sample(self, z: torch.Tensor, labels: torch.Tensor, guidance_scale=6.0, eta: float = 1.0,
                num_time_steps: Optional[int] = None, generator: Optional[torch.Generator] = None,
                noises=None, t_stop: int = 0, snapshots: Optional[dict] = None) -> torch.Tensor:
-        """z: [S,C,H,W] fp32 start noise; labels: [S] long.  Guidance is 0.0 for samples whose label is the
-        unconditional id (reference visualization.py:424).  ``noises[t]`` overrides the RNG (tests);
+        """z: [S,C,H,W] fp32 start noise; labels: [S] long.  ``guidance_scale`` / ``eta``: a float or one value per
+        sample.  Guidance is 0.0 for samples whose label is the unconditional id (reference visualization.py:424).  ``noises[t]`` overrides the RNG (tests);
         ``t_stop>0`` stops after step t_stop (bounded timing runs) and returns the un-clamped latent.
         ``snapshots``: a dict whose keys are the timesteps to capture (visualization.py:144-146); it is filled
         with the clamped latent after those steps (key 0 = the final image)."""
@@ -99,7 +101,7 @@ class CFGSampler:
         dev = z.device
         beta, abar = self.sched.beta_cpu, self.sched.alpha_bar_cpu
         labels = labels.to(dev).long()
-        g = torch.full((S,), float(guidance_scale), dtype=torch.float32)
+        g = torch.as_tensor(guidance_scale, dtype=torch.float32).expand(S).clone()
         g[labels.cpu() == self.uncond_id] = 0.0
         table = self.table.to(dev)
         ctx = torch.cat([table[torch.full_like(labels, self.uncond_id)], table[labels]]).contiguous()
@@ -107,6 +109,7 @@ class CFGSampler:
         zz = torch.empty((2 * S, *z.shape[1:]), dtype=torch.float32, device=dev)
         tt = torch.empty((2 * S,), dtype=torch.long, device=dev)
         steps = [t for t in range(T - 1, -1, -1) if t >= t_stop]
+        any_eta = bool((torch.as_tensor(eta) > 0.0).any())
         # every step's coefficient rows in one upload (host fp32 math identical to the reference's)
         coefs = torch.stack([step_coefficients(beta, abar, t, g, eta, S, final=(t == 0)) for t in steps]).to(dev)
         # (Replaying the forward as a captured HIP graph was measured: 7.56 vs 7.28 ms/step eager at B=176 -- the
@@ -118,7 +121,7 @@ class CFGSampler:
             tt.fill_(t)
             v, _ = model._fwd(zz, tt, ctx)
             noise = None
-            if (not final) and t > 1 and eta > 0.0:
+            if (not final) and t > 1 and any_eta:
                 if noises is not None and t in noises:
                     noise = noises[t].to(dev)
                 else:
@@ -168,3 +171,49 @@ class CFGSampler:
                 noise = zz[:n]  # unused (coef[4] == 0)
             z[:n] = K.cfg_ddpm_step(z[:n].contiguous(), v[:n], v[n:], noise, coef)
         return z.index_select(0, inv.to(dev))
+
+    @torch.no_grad()
+    def sample_dpm(self, z: torch.Tensor, labels: torch.Tensor, dpm, cfg_scale=6.0,
+                   num_inference_steps: int = 50) -> torch.Tensor:
+        """DPM-Solver++(2M) sampling (reference visualization.py:480-534) for a whole batch: per step ONE UNet forward
+        over [uncond; cond] and ONE fused kernel (``dm_cfg_dpmpp2m_step``).  ``dpm`` is a
+        ``dpm_solver.DPMSolverMultistepScheduler``; ``cfg_scale`` a float or one value per sample.  As in the reference
+        (:513-526) guidance is applied only where cfg_scale > 1.0: the other samples take the conditional branch alone
+        (callers pass 0.0 for the unconditional label, whose context row is the null embedding).  When no sample is
+        guided the uncond half of the batch is not run at all.  Returns the final latents, un-clamped, like the reference."""
+        from . import kernels as K
+        model = self.model
+        model.eval()
+        S, dev = z.shape[0], z.device
+        labels = labels.to(dev).long()
+        g = torch.as_tensor(cfg_scale, dtype=torch.float32).expand(S).clone()
+        g[g <= 1.0] = 1.0                                   # 1.0 = "conditional branch only" for the kernel
+        guided = bool((g != 1.0).any())
+        table = self.table.to(dev)
+        ctx_c = table[labels]
+        ctx = torch.cat([table[torch.full_like(labels, self.uncond_id)], ctx_c]).contiguous() if guided else ctx_c.contiguous()
+        dpm.set_timesteps(num_inference_steps, device=dev)
+        steps = [int(t) for t in dpm.timesteps.tolist()]
+        rows = []
+        for i in range(len(steps)):
+            a_s, s_s, ratio, cc, inv_r0, second = dpm.step_coefficients(i, have_history=(i >= 1))
+            row = torch.stack([torch.tensor(0.0), a_s, s_s, ratio, cc, inv_r0, torch.tensor(1.0 if second else 0.0),
+                               torch.tensor(0.0)]).float()
+            rows.append(row[None, :].repeat(S, 1))
+        coefs = torch.stack(rows)
+        coefs[:, :, 0] = g
+        coefs = coefs.to(dev)
+        z = z.contiguous().float().clone()
+        m_prev = z                                           # not read on the first (first-order) step
+        n_in = 2 * S if guided else S
+        zz = torch.empty((n_in, *z.shape[1:]), dtype=torch.float32, device=dev)
+        tt = torch.empty((n_in,), dtype=torch.long, device=dev)
+        for i, t in enumerate(steps):
+            zz[:S].copy_(z)
+            if guided:
+                zz[S:].copy_(z)
+            tt.fill_(t)
+            v, _ = model._fwd(zz, tt, ctx)
+            v_u, v_c = (v[:S], v[S:]) if guided else (v, v)
+            z, m_prev = K.cfg_dpmpp2m_step(z, v_u, v_c, m_prev, coefs[i])
+        return z

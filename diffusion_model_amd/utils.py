@@ -33,8 +33,10 @@ class DDPM_beta_t_linear_scheduler(nn.Module):
     def __init__(self, num_steps: int = 1000):
         super().__init__()
         beta = torch.linspace(1e-4, 0.02, num_steps, requires_grad=False)
+        self.T = num_steps
+        self.beta_cpu, self.alpha_bar_cpu = beta, torch.cumprod(1 - beta, dim=0)   # fp32 host copies (sampler scalars)
         self.beta_t = beta.to(device)
-        self.alpha_t = torch.cumprod(1 - beta, dim=0).requires_grad_(False).to(device)
+        self.alpha_t = self.alpha_bar_cpu.requires_grad_(False).to(device)
 
     def call(self, t):
         return self.alpha_t[t], self.beta_t[t]

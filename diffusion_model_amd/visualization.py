@@ -1,7 +1,8 @@
 """Monitoring images of the training loop -- SURVEY.md section 8(f) item 2: the callers on the output side of the
 sampler.  Same function names, arguments and output paths as the reference's ``visualization.py``
 (generate_denoise_collage :183-222, generate_random_sample_image :225-261, reconstruct_from_dataset_sample :264-330,
-reconstruct_sweep :333-401; generate_fixed_seed_class_grid lives in main_stl10.py), so ``main_stl10.train``'s epoch hook
+reconstruct_sweep :333-401, sample_dpm_solver :480-534, generate_fixed_seed_class_grid_dpm :537-617;
+generate_fixed_seed_class_grid lives in main_stl10.py), so ``main_stl10.train``'s epoch hook
 can call them unchanged.
 
 What differs, on purpose:
@@ -192,3 +193,40 @@ def reconstruct_sweep(model, scheduler, loader, epoch: int, device: torch.device
         name = STL10_CLASS_NAMES.get(label, str(label))
         save_image_strip([torch.clamp(x, -1, 1)] + recons, [name] + [f"recon t={t} {name}" for t in t0s],
                          os.path.join(output_dir, f"epoch_{epoch}", f"epoch_{epoch}_reconstruction_sweep.png"))
+
+
+def sample_dpm_solver(model, scheduler, label_id: int, cfg_scale: float, num_inference_steps: int,
+                      device: torch.device, latent_shape: tuple = (1, 3, 96, 96)) -> torch.Tensor:
+    """Reference visualization.py:480-534 (DPM-Solver++ with CFG for v-prediction): same arguments and return value (the
+    final latents, un-clamped).  ``scheduler`` is a ``dpm_solver.DPMSolverMultistepScheduler``; guidance applies only when
+    ``cfg_scale > 1.0`` (:513-526).  ``latent_shape`` defaults to the image-space model's (the reference's default is the
+    latent model's (1,4,32,32), whose VAE is out of scope).  Runs on the fused sampler."""
+    latents = torch.randn(latent_shape, device=device)
+    labels = torch.full((latent_shape[0],), int(label_id), device=device, dtype=torch.long)
+    return _sampler(model, scheduler).sample_dpm(latents, labels, scheduler, cfg_scale=cfg_scale,
+                                                 num_inference_steps=num_inference_steps)
+
+
+def generate_fixed_seed_class_grid_dpm(model, scheduler, epoch: int, step: int, cfg_scale: float,
+                                       num_inference_steps: int, label_ids: List[int], label_names: dict, base_seed: int,
+                                       device: torch.device, output_dir: str,
+                                       latent_shape: tuple = (1, 3, 96, 96)) -> torch.Tensor:
+    """Reference visualization.py:537-617: one sample per label, start noise of label i drawn after
+    ``torch.manual_seed(base_seed + i)``, guidance 0.0 (= none) for the unconditional label (:563), one PNG under
+    ``output_dir/epoch_N``.  All labels run as ONE batched DPM-Solver++ job instead of len(label_ids) serial B=1 runs.
+    (The reference's optional CLIP top-1 caption needs the un-fetchable CLIP model and is left out.)  Also returns the
+    batch of final latents."""
+    zs = []
+    for i in range(len(label_ids)):
+        torch.manual_seed(base_seed + i)
+        zs.append(torch.randn(latent_shape, device=device))
+    labels = torch.tensor(list(label_ids), device=device, dtype=torch.long)
+    g = torch.tensor([0.0 if int(l) == UNCOND_ID else float(cfg_scale) for l in label_ids])
+    out = _sampler(model, scheduler).sample_dpm(torch.cat(zs), labels, scheduler, cfg_scale=g,
+                                                num_inference_steps=num_inference_steps)
+    path = os.path.join(output_dir, f"epoch_{epoch}",
+                        f"epoch_{epoch}_step_{step}_dpm_solver_cfg{cfg_scale}_steps{num_inference_steps}.png")
+    save_image_strip([out[i:i + 1] for i in range(out.shape[0])], [label_names.get(int(l), str(l)) for l in label_ids],
+                     path)
+    print(f"Saved: {path}")
+    return out

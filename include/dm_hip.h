@@ -190,6 +190,15 @@ int dm_mse_loss_fwd_bwd(const float* out, const float* v, const float* w, float 
  * Replaces main_stl10.py:130-136 + visualization.py:92-109,144-152. */
 int dm_cfg_ddpm_step(const float* z, const float* v_uncond, const float* v_cond, const float* noise,
                      const float* coef, float* z_out, int B, long chw, dm_stream_t stream);
+/* One fused DPM-Solver++(2M, midpoint) step for the v-prediction model with CFG: what
+ * visualization.py:509-530 does per step through diffusers' DPMSolverMultistepScheduler.step
+ * (prediction_type "v_prediction", algorithm_type "dpmsolver++", solver_order 2; main_stl10.py:676-684).
+ * coef[b][8] = {guidance (1.0 = conditional branch only, visualization.py:524-526), alpha_s, sigma_s,
+ * sigma_t/sigma_s, alpha_t*(exp(-h)-1), 1/r0, second-order flag, unused};
+ * x0 = alpha_s z - sigma_s v_hat -> x0_out;  z_out = ratio z - c x0 [- c/2 (1/r0)(x0 - x0_prev)].
+ * x0_prev is read only when the flag is set (pass any valid pointer otherwise). */
+int dm_cfg_dpmpp2m_step(const float* z, const float* v_uncond, const float* v_cond, const float* x0_prev,
+                        const float* coef, float* z_out, float* x0_out, int B, long chw, dm_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer */
 long dm_sqnorm_workspace_bytes(void);

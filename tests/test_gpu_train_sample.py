@@ -414,3 +414,126 @@ def test_visualization_batched_jobs(tmp_path):
         import numpy as np
         a = torch.from_numpy(np.asarray(im.convert("L"), dtype=np.float32))
         assert float(a.std()) > 1.0  # not a blank sheet
+
+
+# --------------------------------------------------------------------------- faster samplers
+def _dpm(T=500):
+    from diffusion_model_amd.dpm_solver import DPMSolverMultistepScheduler
+    return DPMSolverMultistepScheduler(num_train_timesteps=T, beta_start=0.00085, beta_end=0.012,
+                                       beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                       algorithm_type="dpmsolver++", solver_order=2)
+
+
+def test_dpm_solver_fused_step_and_batched_sampler(tmp_path):
+    """DPM-Solver++(2M) on the fused kernel (reference visualization.py:480-534 over diffusers' scheduler, PARITY
+    UNPINNED: diffusers absent and un-pinned, no reference fixture) against the numpy oracle: (1) the step kernel alone
+    with prescribed model outputs, fp32; (2) the whole batched sampler against the oracle walk over the CPU fp32 oracle
+    UNet, bf16 tolerance; (3) the drop-in functions and their output file."""
+    import numpy as np
+    from PIL import Image
+    from oracle import dpm_solver_ref as R
+    from diffusion_model_amd import kernels as K, utils, visualization as V
+    from diffusion_model_amd.sampler import CFGSampler
+    d = dev()
+    # (1) kernel walk with prescribed v_u / v_c per step, per-sample guidance (1.0 = conditional branch only)
+    n, S = 7, 4
+    s = _dpm()
+    s.set_timesteps(n)
+    sig_tr, _ = R.training_sigmas(500, 0.00085, 0.012)
+    ts, sig = R.inference_grid(500, n, sig_tr)
+    g = torch.Generator().manual_seed(5)
+    gs = torch.tensor([6.0, 1.0, 3.0, 1.0])
+    vu = {int(t): torch.randn(S, 3, 16, 16, generator=g) for t in ts}
+    vc = {int(t): torch.randn(S, 3, 16, 16, generator=g) for t in ts}
+    z0 = torch.randn(S, 3, 16, 16, generator=g)
+
+    def v_hat(x, t):
+        gg = gs.view(-1, 1, 1, 1).numpy()
+        return np.where(gg == 1.0, vc[t].numpy(), vu[t].numpy() + gg * (vc[t].numpy() - vu[t].numpy())).astype(np.float32)
+
+    ref = R.sample(v_hat, z0.numpy(), ts, sig)
+    z = z0.to(d)
+    m = z
+    for i, t in enumerate(ts):
+        a_s, s_s, ratio, cc, inv_r0, second = s.step_coefficients(i, have_history=(i >= 1))
+        assert second == (1 <= i < n - 1)
+        row = torch.stack([torch.tensor(0.0), a_s, s_s, ratio, cc, inv_r0, torch.tensor(float(second)), torch.tensor(0.0)])
+        coef = row[None].repeat(S, 1).float()
+        coef[:, 0] = gs
+        z, m = K.cfg_dpmpp2m_step(z, vu[int(t)].to(d), vc[int(t)].to(d), m, coef.to(d))
+    assert_close(z.cpu(), torch.from_numpy(ref), 2e-5, "DPM-Solver++ kernel walk")
+    assert torch.equal(z, m)                                        # final sigma = 0: sample == last data prediction
+
+    # (2) batched sampler on the HIP UNet vs the oracle walk on the CPU fp32 oracle UNet
+    model, sd0 = make_model(seed=6)
+    model.eval()
+    table = utils._load_clip_context_table()
+    spec = oref.UNetSpec(**STL)
+    labels = torch.tensor([2, 10, 7])
+    cfg = torch.tensor([6.0, 0.0, 6.0])                            # 0.0 for the unconditional label (visualization.py:563)
+    zs = torch.randn(3, 3, 32, 32, generator=g)
+    smp = CFGSampler(model, utils.DDPM_beta_t_cosine_scheduler(500), table, uncond_id=10)
+    n2 = 6
+    got = smp.sample_dpm(zs.to(d), labels, _dpm(), cfg_scale=cfg, num_inference_steps=n2)
+    ts2, sig2 = R.inference_grid(500, n2, sig_tr)
+    outs = []
+    for i in range(3):
+        ctx_c, ctx_u = table[labels[i:i + 1]], table[torch.tensor([10])]
+
+        def v_fn(x, t, i=i, ctx_c=ctx_c, ctx_u=ctx_u):
+            xt, tt = torch.from_numpy(x), torch.tensor([t])
+            with torch.no_grad():
+                v_c = oref.unet_forward(sd0, spec, xt, tt, ctx_c)
+                if float(cfg[i]) > 1.0:                            # visualization.py:513-526
+                    v_u = oref.unet_forward(sd0, spec, xt, tt, ctx_u)
+                    return (v_u + float(cfg[i]) * (v_c - v_u)).numpy()
+                return v_c.numpy()
+
+        outs.append(torch.from_numpy(R.sample(v_fn, zs[i:i + 1].numpy(), ts2, sig2)))
+    assert_close(got.cpu(), torch.cat(outs), 3e-2, "latents after 6 DPM-Solver++ steps")
+    # un-guided batch: the uncond half is not run, result equals the guided-batch row of the same sample
+    alone = smp.sample_dpm(zs[1:2].to(d), labels[1:2], _dpm(), cfg_scale=0.0, num_inference_steps=n2)
+    assert_close(alone, got[1:2], 2e-2, "cond-only path")
+
+    # (3) drop-ins: reference signatures, the reference's output path
+    lat = V.sample_dpm_solver(model, _dpm(), 3, 6.0, 4, d, latent_shape=(1, 3, 32, 32))
+    assert tuple(lat.shape) == (1, 3, 32, 32) and bool(torch.isfinite(lat).all())
+    out = V.generate_fixed_seed_class_grid_dpm(model, _dpm(), 7, 1, 5.0, 4, [0, 4, 10], V.STL10_CLASS_NAMES, 42, d,
+                                               str(tmp_path), latent_shape=(1, 3, 32, 32))
+    assert tuple(out.shape) == (3, 3, 32, 32)
+    im = Image.open(tmp_path / "epoch_7" / "epoch_7_step_1_dpm_solver_cfg5.0_steps4.png")
+    assert im.width > 3 * 60 and float(np.asarray(im.convert("L"), dtype=np.float32).std()) > 1.0
+
+
+def test_inference_sweeps_batched(tmp_path):
+    """inference_sweeps.run_sweep drop-in: every (eta, cfg, label) cell of a schedule is a sample of one batched job with
+    per-sample coefficient rows; cells must equal the same sample run alone with scalar arguments, files at the reference's
+    paths (inference_sweeps.py:136-138), cosine and linear schedules."""
+    from diffusion_model_amd import inference_sweeps as SW, utils
+    from diffusion_model_amd.sampler import CFGSampler
+    model, _ = make_model(seed=8)
+    model.eval()
+    table = utils._load_clip_context_table()
+    T, labels = 6, [1, 10]
+    grids = SW.run_sweep(None, ["cosine", "linear"], [0.0, 3.0], [0.0, 1.0], labels, 42, str(tmp_path), model=model,
+                         num_steps=T, size=32)
+    assert len(grids) == 8
+    for sname in ("cosine", "linear"):
+        for cfg in (0.0, 3.0):
+            for eta in (0.0, 1.0):
+                tag = f"{sname}_cfg{cfg}_eta{eta}"
+                assert (tmp_path / sname / f"grid_{tag}.png").exists()
+                assert tuple(grids[tag].shape) == (2, 3, 32, 32) and float(grids[tag].abs().max()) <= 1.0
+    # an eta = 0 cell (no RNG) against the same samples run alone with scalar guidance / eta
+    zs = []
+    for idx in range(len(labels)):
+        torch.manual_seed(42 + idx)
+        zs.append(torch.randn(1, 3, 32, 32, device=dev()))
+    for sname, sched in (("cosine", utils.DDPM_beta_t_cosine_scheduler(T)), ("linear", utils.DDPM_beta_t_linear_scheduler(T))):
+        smp = CFGSampler(model, sched, table, uncond_id=10)
+        alone = smp.sample(torch.cat(zs), torch.tensor(labels), guidance_scale=3.0, eta=0.0, num_time_steps=T)
+        assert_close(grids[f"{sname}_cfg3.0_eta0.0"], alone, 2e-2, f"{sname} sweep cell vs stand-alone run")
+    # eta changes the result where noise is injected, guidance changes it for the conditional label only
+    assert not torch.allclose(grids["cosine_cfg3.0_eta0.0"], grids["cosine_cfg3.0_eta1.0"])
+    assert not torch.allclose(grids["cosine_cfg0.0_eta0.0"][0], grids["cosine_cfg3.0_eta0.0"][0])
+    assert_close(grids["cosine_cfg0.0_eta0.0"][1], grids["cosine_cfg3.0_eta0.0"][1], 2e-2, "uncond label ignores cfg")

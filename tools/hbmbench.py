@@ -50,6 +50,10 @@ for S in (88, 704):
     coef = torch.rand(S, 8, device=dev)
     out = torch.empty_like(z)
     report(f"cfg_ddpm_step S={S}", timeit(lambda: K.cfg_ddpm_step(z, vu, vc, nz, coef, out=out)), 20 * z.numel())
+    coef2 = coef.clone(); coef2[:, 6] = 1.0   # second-order rows: reads z, v_u, v_c, x0_prev; writes z', x0
+    x0o = torch.empty_like(z)
+    report(f"cfg_dpmpp2m_step S={S}", timeit(lambda: K.cfg_dpmpp2m_step(z, vu, vc, nz, coef2, out=out, x0_out=x0o)),
+           24 * z.numel())
 x, e = torch.randn(B, 3, 96, 96, device=dev), torch.randn(B, 3, 96, 96, device=dev)
 ab = torch.rand(B, device=dev)
 report("qsample_vtarget B=64", timeit(lambda: K.qsample_vtarget(x, e, ab)), 16 * x.numel())
