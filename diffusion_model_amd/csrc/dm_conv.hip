@@ -523,6 +523,9 @@ int launch_gemm_stream_v(const ConvParams& p, hipStream_t st) {
   int gx = 1024 / gy;  // up to four resident workgroups per CU in total (VGPR/LDS permitting)
   if (gx < 1) gx = 1;
   if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id (x + y * gx): with gx a multiple of 8 the gy
+  // workgroups that stream the same X rows sit on one XCD and share them through its L2.
+  if (gy > 1 && gx > 8) gx &= ~7;
   hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), LDS, st, p, ntiles);
   DM_LAUNCH_CHECK();
   return DM_OK;
