@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int PART_LDS = 512;  // (split, group) partials staged in LDS by the apply kernels
+constexpr int MAX_C = 1024;    // widest GroupNorm (latent-model widths, utils.py:145-156); 256 threads x 8 channels x rows
 struct Wf { float n, mean, m2; };
 __device__ __forceinline__ Wf wf_merge(Wf a, Wf b) {
   const float n = a.n + b.n;
@@ -161,11 +162,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
                                                              float* __restrict__ ws, float* __restrict__ wsg,
                                                              int HW, int C, int G, int nsplit, int act) {
   __shared__ float red[2][256 * 8 + 8];
+  __shared__ float s_grp[64 * 2];
   const int b = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
   const int tpp = C >> 3, ppi = 256 / tpp, cpg = C / G;
   const int c0 = (tid % tpp) * 8, prow = tid / tpp;
   const int g = c0 / cpg;
   const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+  if (cpg > 64 && tid < 2 * G) s_grp[tid] = 0.f;  // ordered before its use by the barrier below
   float ga[8], be[8], add[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -214,14 +217,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
     }
     float* o = ws + (((long)b * nsplit + split) * C + c) * 2;
     o[0] = a1; o[1] = a2;
-    // group partials {sum_c gamma*S1, sum_c gamma*S2}: all the apply pass needs (C <= 256: one channel per thread;
-    // the cpg channels of a group sit in consecutive lanes of one wave)
+    // group partials {sum_c gamma*S1, sum_c gamma*S2}: all the apply pass needs.  Consecutive lanes hold consecutive
+    // channels: a group of cpg <= 64 channels sits inside one wave (shuffles only); wider groups (C/G > 64, the
+    // latent-model widths) combine their per-wave sums through LDS.
     float g1 = gamma[c] * a1, g2 = gamma[c] * a2;
-    for (int o2 = cpg >> 1; o2 > 0; o2 >>= 1) { g1 += __shfl_xor(g1, o2, 64); g2 += __shfl_xor(g2, o2, 64); }
-    if ((c % cpg) == 0) {
-      float* og = wsg + (((long)b * nsplit + split) * G + c / cpg) * 2;
-      og[0] = g1; og[1] = g2;
+    const int span = cpg < 64 ? cpg : 64;
+    for (int o2 = span >> 1; o2 > 0; o2 >>= 1) { g1 += __shfl_xor(g1, o2, 64); g2 += __shfl_xor(g2, o2, 64); }
+    if (cpg <= 64) {
+      if ((c % cpg) == 0) {
+        float* og = wsg + (((long)b * nsplit + split) * G + c / cpg) * 2;
+        og[0] = g1; og[1] = g2;
+      }
+    } else if ((c & 63) == 0) {
+      atomicAdd(&s_grp[(c / cpg) * 2], g1);
+      atomicAdd(&s_grp[(c / cpg) * 2 + 1], g2);
     }
+  }
+  if (cpg > 64) {
+    __syncthreads();
+    if (tid < 2 * G) wsg[((long)b * nsplit + split) * G * 2 + tid] = s_grp[tid];
   }
 }
 
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ wsg, int nsplit, const bf16* __restrict__ add_in, long ldadd,
     bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
     uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum) {
-  __shared__ float s_s1[256], s_m1[64], s_m2[64];
+  __shared__ float s_s1[MAX_C], s_m1[64], s_m2[64];
   __shared__ float s_part[PART_LDS * 2];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
@@ -369,8 +383,8 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
                               const float* beta, void* y, long ldy, float* stats, int B, int HW, int C, int G,
                               float eps, int act_silu, void* workspace, long ws_bytes, dm_stream_t stream) {
   DM_REQUIRE(x && y && gamma && beta && stats && workspace);
-  DM_REQUIRE(C % 8 == 0 && C <= 256 * 8 / 8 * 8 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0);
-  DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 256);
+  DM_REQUIRE(C % 8 == 0 && C <= MAX_C && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0);
+  DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && ldy % 8 == 0);
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G));
   const int ns = pick_split(B, HW);
   hipStream_t st = (hipStream_t)stream;
@@ -389,7 +403,7 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
                               int G, int act_silu, float drop_p, unsigned long long drop_seed, float* dx_colsum,
                               void* workspace, long ws_bytes, dm_stream_t stream) {
   DM_REQUIRE(x && dy && dx && gamma && beta && stats && workspace && dgamma && dbeta);
-  DM_REQUIRE(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0 && C <= 256);
+  DM_REQUIRE(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0 && C <= MAX_C);
   DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!add_in || ldadd % 8 == 0));
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G) && drop_p >= 0.f && drop_p < 1.f);
   const int ns = pick_split(B, HW);

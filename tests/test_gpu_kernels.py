@@ -186,7 +186,8 @@ def test_wgrad_silu_in_and_kvalid(K):
 
 
 # ------------------------------------------------------------------ GroupNorm + SiLU
-@pytest.mark.parametrize("B,H,W,C", [(2, 12, 12, 64), (3, 24, 24, 128), (2, 16, 16, 256), (1, 96, 96, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 12, 64), (3, 24, 24, 128), (2, 16, 16, 256), (1, 96, 96, 64),
+                                     (2, 16, 16, 512), (2, 8, 8, 1024)])   # last two: latent-model widths (utils.py:145-156)
 @pytest.mark.parametrize("with_add", [False, True])
 def test_gn_silu(K, B, H, W, C, with_add):
     x = q16(rnd(B, C, H, W, seed=1) * 1.5 + 0.3).requires_grad_()
@@ -396,13 +397,13 @@ def test_gn_silu_bwd_fused_column_sums():
     """dm_gn_silu_bwd(dx_colsum=...): per-sample channel sums of the written dx, accumulated (+=) in the same pass."""
     from diffusion_model_amd import kernels as K
     torch.manual_seed(3)
-    B, H, W, C, G = 3, 12, 10, 64, 8
-    x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
-    dy = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
-    gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
-    _, stats = K.gn_silu_fwd(x, gam, bet, G)
-    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    cs = torch.full((B, C), 0.5, device="cuda")
-    dx = K.gn_silu_bwd(x, dy, gam, bet, stats, G, dg, db, drop_p=0.1, drop_seed=7, colsum_out=cs)
-    ref = dx.float().sum(dim=(1, 2)) + 0.5
-    assert torch.allclose(cs, ref, rtol=1e-4, atol=1e-3), float((cs - ref).abs().max())
+    for B, H, W, C, G in ((3, 12, 10, 64, 8), (2, 8, 8, 1024, 8)):   # the second: latent-model width
+        x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
+        dy = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16)
+        gam, bet = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        _, stats = K.gn_silu_fwd(x, gam, bet, G)
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        cs = torch.full((B, C), 0.5, device="cuda")
+        dx = K.gn_silu_bwd(x, dy, gam, bet, stats, G, dg, db, drop_p=0.1, drop_seed=7, colsum_out=cs)
+        ref = dx.float().sum(dim=(1, 2)) + 0.5
+        assert torch.allclose(cs, ref, rtol=1e-4, atol=1e-3), float((cs - ref).abs().max())
