@@ -1,5 +1,5 @@
 // Flash-style fused attention (forward + backward) for the UNet's self- and cross-attention:
-// 8 heads, head_dim in {8,16,32}, Nq in {576,2304,9216}, Nk = Nq (self) or the number of
+// 8 heads, head_dim in {8,16,32} (flash / few-token kernels) or {64,128} (wide-head kernels), Nq in {576,2304,9216}, Nk = Nq (self) or the number of
 // context tokens (cross; 1 for the CLIP table).  No N x N matrix ever reaches memory.
 //
 // Register-resident P: the score tile is computed TRANSPOSED (S^T = K Q^T, keys on MFMA rows,
@@ -350,8 +350,7 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const AttnParams p
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) s += (float)ov[t] * (float)dv[t];
-    if (sub >= 2) s += __shfl_xor(s, 1, 64);
-    if (sub >= 4) s += __shfl_xor(s, 2, 64);
+    for (int o2 = 1; o2 < sub; o2 <<= 1) s += __shfl_xor(s, o2, 64);  // sub = 1..16 threads per head
     if ((tid % sub) == 0) {
       const long b = row / p.Nq, q = row % p.Nq;
       p.delta[(b * p.H + h) * p.Nq + q] = s;
@@ -800,6 +799,188 @@ __global__ void attn_small_finish_kernel(const AttnParams p, const float* __rest
   }
 }
 
+
+// ---------------------------------------------------------------- wide heads (hd = 64, 128)
+// The latent-diffusion model's self-attention (utils.py:145-156: 512 and 1024 channels over 8 heads, at most 256
+// tokens at 32x32 latents).  Plain fp32 VALU kernels -- at these sizes the attention is a few percent of a step that
+// the wide convolutions dominate, so they are written for exactness and simplicity, not for the MFMA pipe:
+// thread = (row, eighth of the head): 8 consecutive lanes own one query (or key) row, each hd/8 of its dimensions;
+// dot products combine over the 8 lanes with three shuffles; the other operand's rows are staged 32 at a time in LDS
+// and read as broadcasts.  Same dropout words as the few-token kernels (row = (b*H+h)*Nq + q, column = key).
+template <int HD>
+__device__ __forceinline__ void wide_stage(bf16* sA, const bf16* a, long lda, bf16* sB, const bf16* b, long ldb, long base,
+                                           int r0, int n, int hoff, int tid) {
+  constexpr int PPR = HD / 8;  // 16-byte pieces per row
+  for (int i = tid; i < 32 * PPR; i += 256) {
+    const int r = i / PPR, pc = i % PPR;
+    u32x4 va = {0u, 0u, 0u, 0u}, vb = va;
+    if (r0 + r < n) {
+      va = *reinterpret_cast<const u32x4*>(a + (base + r0 + r) * lda + hoff + pc * 8);
+      vb = *reinterpret_cast<const u32x4*>(b + (base + r0 + r) * ldb + hoff + pc * 8);
+    }
+    *reinterpret_cast<u32x4*>(sA + r * HD + pc * 8) = va;
+    *reinterpret_cast<u32x4*>(sB + r * HD + pc * 8) = vb;
+  }
+}
+__device__ __forceinline__ float wide_sum8(float s) {
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  return s;
+}
+template <int HD>
+__device__ __forceinline__ void wide_load_row(const bf16* base, bool ok, float scale, float (&f)[HD / 8]) {
+#pragma unroll
+  for (int d0 = 0; d0 < HD / 8; d0 += 8) {
+    bf16x8 v = {};
+    if (ok) v = *reinterpret_cast<const bf16x8*>(base + d0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[d0 + j] = (float)v[j] * scale;
+  }
+}
+template <int HD>
+__device__ __forceinline__ void wide_store_row(bf16* base, const float (&f)[HD / 8], float scale) {
+#pragma unroll
+  for (int d0 = 0; d0 < HD / 8; d0 += 8) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)(f[d0 + j] * scale);
+    *reinterpret_cast<bf16x8*>(base + d0) = v;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) {
+  constexpr int DPT = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
+  __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
+  const int tid = threadIdx.x, ql = tid >> 3, part = tid & 7;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
+  const int q = blockIdx.x * 32 + ql;
+  const bool q_ok = q < p.Nq;
+  float qf[DPT], acc[DPT];
+  wide_load_row<HD>(p.q + ((long)b * p.Nq + q) * p.ldq + hoff + part * DPT, q_ok, p.scale, qf);
+#pragma unroll
+  for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+    __syncthreads();
+    wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
+    __syncthreads();
+    const int kn = min(32, p.Nk - k0);
+    for (int j = 0; j < kn; ++j) {
+      const bf16* kr = sK + j * HD + part * DPT;
+      const bf16* vr = sV + j * HD + part * DPT;
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) sc += qf[d] * (float)kr[d];
+      sc = wide_sum8(sc);
+      const float mn = fmaxf(m, sc);
+      const float alpha = __expf(m - mn), pj = __expf(sc - mn);
+      l = l * alpha + pj;
+      float pd = pj;
+      if (p.thresh) pd = dm_keep16(dm_drop_bits(rs, (uint32_t)(k0 + j) >> 1), (uint32_t)(k0 + j), p.thresh) ? pj * p.inv_keep : 0.f;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) acc[d] = acc[d] * alpha + pd * (float)vr[d];
+      m = mn;
+    }
+  }
+  if (q_ok) {
+    wide_store_row<HD>(p.o + ((long)b * p.Nq + q) * p.ldo + hoff + part * DPT, acc, 1.f / l);
+    if (part == 0) p.lse[(long)bh * p.Nq + q] = m + __logf(l);
+  }
+}
+
+// dQ: the forward's mapping; P is rebuilt from the saved log-sum-exp.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p) {
+  constexpr int DPT = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
+  __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
+  const int tid = threadIdx.x, ql = tid >> 3, part = tid & 7;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
+  const int q = blockIdx.x * 32 + ql;
+  const bool q_ok = q < p.Nq;
+  float qf[DPT], df[DPT], acc[DPT];
+  wide_load_row<HD>(p.q + ((long)b * p.Nq + q) * p.ldq + hoff + part * DPT, q_ok, p.scale, qf);
+  wide_load_row<HD>(p.d_o + ((long)b * p.Nq + q) * p.lddo + hoff + part * DPT, q_ok, 1.f, df);
+#pragma unroll
+  for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
+  const float L = q_ok ? p.lse[(long)bh * p.Nq + q] : 0.f;
+  const float dl = q_ok ? p.delta[(long)bh * p.Nq + q] : 0.f;
+  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+    __syncthreads();
+    wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
+    __syncthreads();
+    const int kn = min(32, p.Nk - k0);
+    for (int j = 0; j < kn; ++j) {
+      const bf16* kr = sK + j * HD + part * DPT;
+      const bf16* vr = sV + j * HD + part * DPT;
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) { sc += qf[d] * (float)kr[d]; dp += df[d] * (float)vr[d]; }
+      sc = wide_sum8(sc); dp = wide_sum8(dp);
+      const float pj = __expf(sc - L);
+      float zf = 1.f;
+      if (p.thresh) zf = dm_keep16(dm_drop_bits(rs, (uint32_t)(k0 + j) >> 1), (uint32_t)(k0 + j), p.thresh) ? p.inv_keep : 0.f;
+      const float ds = pj * (zf * dp - dl);
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) acc[d] += ds * (float)kr[d];
+    }
+  }
+  if (q_ok) wide_store_row<HD>(p.dq + ((long)b * p.Nq + q) * p.lddq + hoff + part * DPT, acc, p.scale);
+}
+
+// dK, dV: thread = (key, eighth of the head); queries and their dO rows staged 32 at a time.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams p) {
+  constexpr int DPT = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16 sQ[32 * HD];
+  __shared__ __attribute__((aligned(16))) bf16 sD[32 * HD];
+  __shared__ float sL[32], sDl[32];
+  const int tid = threadIdx.x, kl = tid >> 3, part = tid & 7;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
+  const int key = blockIdx.x * 32 + kl;
+  const bool k_ok = key < p.Nk;
+  float kf[DPT], vf[DPT], dk[DPT], dv[DPT];
+  wide_load_row<HD>(p.k + ((long)b * p.Nk + key) * p.ldk + hoff + part * DPT, k_ok, p.scale, kf);
+  wide_load_row<HD>(p.v + ((long)b * p.Nk + key) * p.ldv + hoff + part * DPT, k_ok, 1.f, vf);
+#pragma unroll
+  for (int d = 0; d < DPT; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int q0 = 0; q0 < p.Nq; q0 += 32) {
+    __syncthreads();
+    wide_stage<HD>(sQ, p.q, p.ldq, sD, p.d_o, p.lddo, (long)b * p.Nq, q0, p.Nq, hoff, tid);
+    if (tid < 32) {
+      const bool ok = q0 + tid < p.Nq;
+      sL[tid] = ok ? p.lse[(long)bh * p.Nq + q0 + tid] : 0.f;
+      sDl[tid] = ok ? p.delta[(long)bh * p.Nq + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    const int qn = min(32, p.Nq - q0);
+    for (int i = 0; i < qn; ++i) {
+      const bf16* qr = sQ + i * HD + part * DPT;
+      const bf16* dr = sD + i * HD + part * DPT;
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) { sc += kf[d] * (float)qr[d]; dp += vf[d] * (float)dr[d]; }
+      sc = wide_sum8(sc); dp = wide_sum8(dp);
+      const float pj = __expf(sc - sL[i]);
+      float zf = 1.f;
+      if (p.thresh) {
+        const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q0 + i));
+        zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
+      }
+      const float ds = pj * (zf * dp - sDl[i]), pz = pj * zf;
+#pragma unroll
+      for (int d = 0; d < DPT; ++d) { dk[d] += ds * (float)qr[d]; dv[d] += pz * (float)dr[d]; }
+    }
+  }
+  if (k_ok) {
+    wide_store_row<HD>(p.dk + ((long)b * p.Nk + key) * p.lddk + hoff + part * DPT, dk, p.scale);
+    wide_store_row<HD>(p.dv + ((long)b * p.Nk + key) * p.lddv + hoff + part * DPT, dv, 1.f);
+  }
+}
+
 // ---------------------------------------------------------------- one context token (the CLIP table)
 // With a single key the softmax is identically 1 -- exactly, in any arithmetic: exp(s - s) / 1 -- so
 //   o[q] = Z[q,h] * v / keep,   lse[q] = scale * q.k,   dS = P o (dP - delta) = 0  =>  dq = dk = 0,
@@ -814,7 +995,7 @@ __device__ __forceinline__ bool onekey_keep(const AttnParams& p, int bh, int q) 
 __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p) {
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
   const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
-  const int sub = p.hd >> 3;  // threads per head: 1, 2 or 4
+  const int sub = p.hd >> 3;  // threads per head: 1, 2, 4, 8 or 16
   const bf16x8 vr = *reinterpret_cast<const bf16x8*>(p.v + (long)b * p.ldv + c8);
   float kf[8];
   bf16x8 vs, vz;
@@ -834,8 +1015,7 @@ __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)qr[j] * kf[j];
-      if (sub >= 2) s += __shfl_xor(s, 1, 64);
-      if (sub >= 4) s += __shfl_xor(s, 2, 64);
+      for (int o2 = 1; o2 < sub; o2 <<= 1) s += __shfl_xor(s, o2, 64);
       if ((tid % sub) == 0) p.lse[(long)bh * p.Nq + q] = s;
     }
     const bool keep = !drop || onekey_keep(p, bh, q);
@@ -865,10 +1045,10 @@ __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p
 #pragma unroll
   for (int j = 0; j < 8; ++j) sAcc[(qs * TPQ * 8) + (tid % TPQ) * 8 + j] = acc[j];
   __syncthreads();
-  if (tid < C) {
+  for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    for (int i = 0; i < QPB; ++i) s += sAcc[i * C + tid];
-    atomicAdd(ws + (long)p.B * C + (long)b * C + tid, s * (drop ? p.inv_keep : 1.f));
+    for (int i = 0; i < QPB; ++i) s += sAcc[i * C + c];
+    atomicAdd(ws + (long)p.B * C + (long)b * C + c, s * (drop ? p.inv_keep : 1.f));
   }
 }
 bool onekey_ok(const AttnParams& p) {
@@ -883,7 +1063,7 @@ bool small_ok(const AttnParams& p) {
 
 int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   DM_REQUIRE(a && a->v && a->o);
-  DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32);
+  DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32 || a->hd == 64 || a->hd == 128);
   DM_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
   // With ONE key the output does not depend on q or k (softmax over one element), so a caller that has no use for
   // the log-sum-exp may pass q = k = lse = NULL, and in backward dq = dk = NULL (both are identically zero).
@@ -934,6 +1114,14 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     if (p.hd == 8) hipLaunchKernelGGL(attn_small_fwd_kernel<8>, g, dim3(256), lds, (hipStream_t)stream, p);
     else if (p.hd == 16) hipLaunchKernelGGL(attn_small_fwd_kernel<16>, g, dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_small_fwd_kernel<32>, g, dim3(256), lds, (hipStream_t)stream, p);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  if (p.hd >= 64) {  // wide heads (latent-model widths): fp32 VALU kernels
+    DM_REQUIRE((p.ldo & 7) == 0);
+    const dim3 g((p.Nq + 31) / 32, p.B * p.H);
+    if (p.hd == 64) hipLaunchKernelGGL(attn_wide_fwd_kernel<64>, g, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_wide_fwd_kernel<128>, g, dim3(256), 0, (hipStream_t)stream, p);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
@@ -995,6 +1183,19 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
   }
   DM_LAUNCH_CHECK();
+  if (p.hd >= 64) {
+    DM_REQUIRE((p.lddq & 7) == 0 && (p.lddk & 7) == 0 && (p.lddv & 7) == 0);
+    const dim3 gk((p.Nk + 31) / 32, p.B * p.H), gqw((p.Nq + 31) / 32, p.B * p.H);
+    if (p.hd == 64) {
+      hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<64>, gk, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_wide_bwd_q_kernel<64>, gqw, dim3(256), 0, st, p);
+    } else {
+      hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<128>, gk, dim3(256), 0, st, p);
+      hipLaunchKernelGGL(attn_wide_bwd_q_kernel<128>, gqw, dim3(256), 0, st, p);
+    }
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
   const dim3 gkv((p.Nk + 63) / 64, p.B * p.H), gq((p.Nq + 127) / 128, p.B * p.H);
   const bool edge = (p.Nk & 63) != 0;
 #define DM_BWD(DT, DROP)                                                                   \

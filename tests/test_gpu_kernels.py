@@ -226,7 +226,10 @@ def ref_attn(q, k, v, heads):
 
 @pytest.mark.parametrize("B,Nq,Nk,C", [(2, 576, 576, 256), (2, 64, 64, 128), (1, 2304, 2304, 128), (2, 200, 1, 64),
                                        (2, 130, 4, 128), (1, 576, 77, 256), (2, 96, 96, 64),
-                                       (2, 300, 16, 256), (1, 100, 17, 64), (3, 2304, 1, 128), (2, 130, 1, 256)])
+                                       (2, 300, 16, 256), (1, 100, 17, 64), (3, 2304, 1, 128), (2, 130, 1, 256),
+                                       # head sizes 64 / 128: the latent model's widths (utils.py:145-156)
+                                       (2, 256, 256, 512), (2, 64, 64, 1024), (1, 100, 37, 512), (2, 45, 3, 1024),
+                                       (2, 130, 1, 512), (2, 64, 1, 1024)])
 def test_attention_fwd_bwd(K, B, Nq, Nk, C):
     heads = 8
     q = q16(rnd(B, Nq, C, seed=1)).requires_grad_()
@@ -281,11 +284,12 @@ def test_attention_fused_qkv_views(K):
     assert_close(o.float(), ref, BF, "attn views")
 
 
-@pytest.mark.parametrize("N,Nk", [(256, 256), (1024, 8), (1024, 1)])  # flash / few-token / one-token path
-def test_attention_dropout_consistency(K, N, Nk):
+@pytest.mark.parametrize("N,Nk,C", [(256, 256, 128), (1024, 8, 128), (1024, 1, 128),   # flash / few-token / one-token
+                                    (256, 256, 512), (512, 1, 1024)])                   # wide heads
+def test_attention_dropout_consistency(K, N, Nk, C):
     """Dropout masks come from a counter RNG; check keep-rate and that the backward uses the forward's mask
     (dV of a one-hot d_o equals P_drop^T restricted to that column)."""
-    B, C, heads, p = 1, 128, 8, 0.25
+    B, heads, p = 1, 8, 0.25
     q = q16(rnd(B, N, C, seed=1)).to(torch.bfloat16)
     k = q16(rnd(B, Nk, C, seed=2)).to(torch.bfloat16)
     v = torch.ones(B, Nk, C, device=dev(), dtype=torch.bfloat16)
