@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--sample-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-latent", action="store_true", help="skip the secondary latent-diffusion UNet leg (1 GPU only)")
     ap.add_argument("--no-elided", action="store_true", help="skip the secondary legs (dropout 0, dead-attention elided)")
     return ap.parse_args()
 
@@ -61,6 +62,70 @@ def build_model(dropout, dev):
     with torch.no_grad():  # zero-init output_conv would make every other gradient exactly 0
         model.output_conv.weight.copy_(torch.randn(model.output_conv.weight.shape, generator=gen) * 0.05)
     return model.to(dev), table
+
+
+def latent_leg(a, dev, table, sched):
+    """Secondary leg: the reference's latent-diffusion UNet configuration (utils.py:145-156: Channels
+    [256,256,512,1024,512], 4 -> 4 channels, 55.9 M parameters) on synthetic 4x32x32 latents -- the same optimizer step
+    (B per micro-batch, accumulation 2, dropout, AdamW+EMA+clip) and a 50-step CFG DPM-Solver++ sampling run.  Latents are
+    N(0,1) (scaled VAE latents have about unit variance); the VAE itself is not part of the path."""
+    from diffusion_model_amd.dpm_solver import DPMSolverMultistepScheduler
+    from diffusion_model_amd.ema import ModelEmaV2
+    from diffusion_model_amd.sampler import CFGSampler
+    from diffusion_model_amd.trainer import Trainer
+    from diffusion_model_amd.unet import UNET
+    torch.manual_seed(0)
+    model = UNET(time_steps=1000, Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False],
+                 input_channels=4, output_channels=4, dropout_prob=a.dropout, context_dim=512)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        model.output_conv.weight.copy_(torch.randn(model.output_conv.weight.shape, generator=gen) * 0.05)
+    n_params = sum(p.numel() for p in model.parameters())
+    model = model.to(dev).train()
+    ema = ModelEmaV2(model, decay=0.995)
+    tr = Trainer(model, sched, lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99), clip=1.0, ema_decay=0.995, accum=2,
+                 total_steps=100 * 79, start_step=20 * 40, low_t_weight=0.01, ema=ema, distributed=False)
+    batches = []
+    for i in range(2):
+        g = torch.Generator(device="cpu").manual_seed(4321 + i)
+        labels = torch.randint(0, 10, (a.batch,), generator=g)
+        labels[torch.rand(a.batch, generator=g) < 0.2] = 10
+        batches.append((torch.randn(a.batch, 4, 32, 32, generator=g).to(dev), table[labels].to(dev).contiguous(),
+                        torch.randint(0, 500, (a.batch,), generator=g).to(dev),
+                        torch.randn(a.batch, 4, 32, 32, generator=g).to(dev)))
+
+    def opt_step():
+        for b in batches:
+            loss = tr.micro_step(*b)
+        return loss
+
+    for _ in range(2):
+        opt_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = opt_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"what": "reference LDM UNet configuration (utils.py:145-156) on synthetic 4x32x32 latents, same optimizer step",
+           "params": n_params, "value": a.steps * 2 * a.batch / dt, "unit": "latents/s", "ms_per_step": dt / a.steps * 1e3,
+           "final_loss": float(loss.item())}
+    S = 88
+    smp = CFGSampler(ema.module, sched, table, uncond_id=10)
+    dpm = DPMSolverMultistepScheduler(num_train_timesteps=500, beta_start=0.00085, beta_end=0.012,
+                                      beta_schedule="scaled_linear", prediction_type="v_prediction",
+                                      algorithm_type="dpmsolver++", solver_order=2)
+    z = torch.randn(S, 4, 32, 32, generator=torch.Generator().manual_seed(42)).to(dev)
+    labels = torch.arange(S) % 11
+    gd = torch.where(labels == 10, 0.0, 6.0)
+    smp.sample_dpm(z, labels, dpm, cfg_scale=gd, num_inference_steps=3)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    xd = smp.sample_dpm(z, labels, dpm, cfg_scale=gd, num_inference_steps=50)
+    torch.cuda.synchronize()
+    dd = time.perf_counter() - t1
+    out["dpm_solver_pp_2m_50_steps"] = {"value": S / dd, "unit": "latents/s", "finite": bool(torch.isfinite(xd).all().item())}
+    return out
 
 
 def time_dominant_kernel(B, dev, reps=20):
@@ -332,6 +397,8 @@ def main():
         out["dead_attention_elided"] = elided
     if sampling:
         out["sampling"] = sampling
+    if world == 1 and not a.no_latent and not a.no_elided:
+        out["latent_unet"] = latent_leg(a, dev, table, sched)
     if not a.no_roofline:
         iso_sec, fl = time_dominant_kernel(a.batch, dev)
         sec = iso_sec

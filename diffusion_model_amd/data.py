@@ -98,3 +98,40 @@ class STL10Loader:
             u8 = self.images.index_select(0, idx)
             x = self.lut.index_select(0, u8.reshape(-1).to(torch.int32)).view(u8.shape)
             yield x, self.labels.index_select(0, idx)
+
+
+class LatentLoader:
+    """Latent-diffusion input: the reference's ``LatentDataset`` (utils.py:70-91) + shuffled
+    ``DataLoader`` as one device-resident loader.  The file is the reference's ``{'latents': [N,4,h,w], 'labels': [N]}``
+    dict of pre-computed VAE latents (``vae_encoder.py``), read with a tensor-only ``torch.load``; every sample is
+    ``latents[i] * scaling_factor`` (:90).  ``scaling_factor`` is the VAE's ``config.scaling_factor`` in the reference
+    (VAE.py:42); the VAE itself cannot be fetched here, so the factor is an argument, defaulting to the published
+    value of ``stabilityai/sd-vae-ft-ema`` (0.18215).  Same iteration / sharding interface as ``STL10Loader``."""
+
+    def __init__(self, latent_path: str, scaling_factor: float = 0.18215, batch_size: int = 64, shuffle: bool = True,
+                 drop_last: bool = False, seed: int = 0, device: Optional[torch.device] = None, rank: int = 0,
+                 world_size: int = 1):
+        d = torch.load(latent_path, map_location="cpu", weights_only=True)
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.latents = d["latents"].float().to(dev)
+        self.labels = torch.as_tensor(d["labels"]).long().to(dev)
+        assert self.latents.ndim == 4 and self.latents.shape[0] == self.labels.shape[0]
+        self.scaling_factor = float(scaling_factor)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
+        self.gen = torch.Generator().manual_seed(int(seed))
+        self.rank, self.world = int(rank), int(world_size)
+        self.n = self.latents.shape[0]
+
+    def __len__(self) -> int:
+        n = (self.n - self.rank + self.world - 1) // self.world
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __getitem__(self, idx: int):
+        return self.latents[idx] * self.scaling_factor, self.labels[idx]
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        order = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
+        order = order[self.rank::self.world].to(self.latents.device)
+        for i in range(len(self)):
+            idx = order[i * self.batch_size:(i + 1) * self.batch_size]
+            yield self.latents.index_select(0, idx) * self.scaling_factor, self.labels.index_select(0, idx)

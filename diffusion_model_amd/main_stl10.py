@@ -69,6 +69,12 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
     reference's end-of-epoch images (:521-524: reconstruction sweep, denoising collage, fixed-seed class grid) are
     written under it every ``monitor_every`` epochs from the EMA weights, each as one batched sampling job."""
     scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
+    if train_loader is None and config.LDM:
+        # reference utils.py:127-132: pre-computed VAE latents (the latent model, utils.py:145-156); no synthetic
+        # stand-in here -- without the file there is nothing to train the latent model on
+        from .data import LatentLoader
+        train_loader = LatentLoader(os.path.join("docs", "data", "imagenet_latents.pt" if config.IMAGE_NET
+                                                 else "stl10_latents.pt"), batch_size=BATCH_SIZE, device=device)
     if train_loader is None:
         try:  # reference: torchvision STL10(root='stl10_data', split='train'), shuffled, batch_size BATCH_SIZE
             from .data import STL10Loader

@@ -79,3 +79,28 @@ def test_loader_exact_batches_unshuffled(tmp_path):
     batches = list(ld)
     assert torch.equal(batches[0][0], normalize_uint8(torch.from_numpy(imgs[:4])))
     assert torch.equal(batches[1][1], torch.from_numpy(labels[4:8]))
+
+
+def test_latent_loader_matches_reference_dataset(tmp_path):
+    """LatentDataset (reference utils.py:70-91): sample i = latents[i] * scaling_factor; loader = shuffled batches of those,
+    sharded by rank like STL10Loader."""
+    import torch
+    from diffusion_model_amd.data import LatentLoader
+    g = torch.Generator().manual_seed(0)
+    lat, lab = torch.randn(10, 4, 8, 8, generator=g), torch.randint(0, 10, (10,), generator=g)
+    path = tmp_path / "stl10_latents.pt"
+    torch.save({"latents": lat, "labels": lab}, path)
+    ld = LatentLoader(str(path), batch_size=4, shuffle=False)
+    assert len(ld) == 3
+    xs, ys = zip(*list(ld))
+    assert [x.shape[0] for x in xs] == [4, 4, 2]
+    assert torch.equal(torch.cat(xs), lat * 0.18215) and torch.equal(torch.cat(ys), lab)
+    x3, y3 = ld[3]
+    assert torch.equal(x3, lat[3] * 0.18215) and int(y3) == int(lab[3])
+    # two ranks see disjoint halves of one shuffled epoch
+    a = LatentLoader(str(path), batch_size=16, seed=5, rank=0, world_size=2, scaling_factor=1.0)
+    b = LatentLoader(str(path), batch_size=16, seed=5, rank=1, world_size=2, scaling_factor=1.0)
+    xa, xb = next(iter(a))[0], next(iter(b))[0]
+    both = torch.cat([xa, xb])
+    assert both.shape[0] == 10
+    assert sorted(float(v) for v in both.flatten(1).sum(1)) == pytest.approx(sorted(float(v) for v in lat.flatten(1).sum(1)))

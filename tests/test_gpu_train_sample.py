@@ -11,16 +11,18 @@ from oracle import unet_ref as oref
 
 pytestmark = pytest.mark.gpu
 STL = dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0)
+LDM_CFG = dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
+               output_channels=4, dropout_prob=0.0, context_dim=512)   # reference utils.py:145-156
 
 
 def dev():
     return torch.device("cuda:0")
 
 
-def make_model(seed=0, dropout=0.0):
+def make_model(seed=0, dropout=0.0, base=None):
     from diffusion_model_amd.unet import UNET
     torch.manual_seed(seed)
-    kw = dict(STL, dropout_prob=dropout)
+    kw = dict(base or STL, dropout_prob=dropout)
     m = UNET(**kw)
     with torch.no_grad():
         m.output_conv.weight.normal_(0, 0.05)
@@ -28,11 +30,16 @@ def make_model(seed=0, dropout=0.0):
     return m.to(dev()), sd
 
 
-def test_train_step_matches_oracle():
+@pytest.mark.parametrize("variant", ["stl10", "latent"])
+def test_train_step_matches_oracle(variant):
+    """``latent``: the same step on the reference's LDM configuration (utils.py:145-156) over 4x32x32 latents (SURVEY 8f
+    item 3) -- q-sample, forward, weighted loss, backward, accumulation, clip, AdamW, EMA against the oracle."""
     from diffusion_model_amd.ema import ModelEmaV2
     from diffusion_model_amd.trainer import Trainer, lr_lambda
     from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
-    model, sd0 = make_model()
+    base = STL if variant == "stl10" else LDM_CFG
+    CH = base["input_channels"]
+    model, sd0 = make_model(base=base)
     model.train()  # dropout_prob = 0: train mode is deterministic
     sched = DDPM_beta_t_cosine_scheduler(500)
     ema = ModelEmaV2(model, decay=0.995)
@@ -43,13 +50,13 @@ def test_train_step_matches_oracle():
     B = 2
     batches = []
     for _ in range(2):
-        x = torch.clamp(torch.randn(B, 3, 32, 32, generator=g) * 0.5, -1, 1)
+        x = torch.clamp(torch.randn(B, CH, 32, 32, generator=g) * 0.5, -1, 1)
         t = torch.randint(0, 500, (B,), generator=g)
-        e = torch.randn(B, 3, 32, 32, generator=g)
+        e = torch.randn(B, CH, 32, 32, generator=g)
         ctx = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
         batches.append((x, ctx, t, e))
     # ---- oracle: two accumulated micro-batches, clip, AdamW, EMA (main_stl10.py:449-516)
-    spec = oref.UNetSpec(**STL)
+    spec = oref.UNetSpec(**base)
     sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
     names = list(sd)
     _, _, abar = dref.cosine_schedule(500)
@@ -540,8 +547,7 @@ def test_inference_sweeps_batched(tmp_path):
 
 
 # --------------------------------------------------------------------------- latent-diffusion UNet variant
-LDM = dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
-           output_channels=4, dropout_prob=0.0, context_dim=512)
+LDM = LDM_CFG
 
 
 @pytest.mark.parametrize("with_context", [True, False])
