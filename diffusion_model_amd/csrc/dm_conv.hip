@@ -710,9 +710,14 @@ extern "C" int dm_gemm(const dm_gemm_args* a, dm_stream_t stream) {
   p.drop_thresh = 0; p.drop_scale = 1.f;
   hipStream_t st = (hipStream_t)stream;
   {
-    // streaming kernel whenever the workgroup's weight slice fits in 64 KiB of LDS
+    // streaming kernel when the workgroup's weight slice fits in 64 KiB of LDS ...
     const int nks = ((a->K + 63) / 64) * 2;
     int rc = 1;
+    // ... and the shape is HBM-bound: from K = 512 up, or K = 256 with more than one 128-column block and many rows, the barrier-
+    // pipelined implicit-GEMM kernel below (weights re-staged per k-step, 64-row wave tiles) is faster
+    // (measured: 16384x512x512 21 vs 27 us, 65536x512x256 28 vs 47 us, 16384x512x1536 43 vs 69 us, 65536x256x256 20 vs 25 us)
+    if ((nks >= 16 && a->M >= 4096) || (nks == 8 && a->N > 128 && a->M >= 65536)) rc = 1;
+    else
     if (a->N % 128 == 0 && nks <= 8 && a->M > 4096) rc = dispatch_gemm_stream<8>(p, st);
     else if (a->N % 64 == 0 && nks <= 16) rc = dispatch_gemm_stream<4>(p, st);
     if (rc <= 0) return rc;
