@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p
     *reinterpret_cast<bf16x8*>(p.o + row * p.ldo + c8) = keep ? (drop ? vs : vr) : vz;
   }
 }
-// ws: [2][B][C] fp32 (dK half stays zero from the memset, dV half accumulates), finished by attn_small_finish_kernel
+// ws: [gridDim.x][B][C] fp32 per-block partial sums of dV (plain stores: no memset before, no atomics, a fixed
+// summation order), summed by attn_onekey_finish_kernel
 __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p, float* __restrict__ ws) {
   __shared__ float sAcc[256 * 8];
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
@@ -1048,7 +1049,18 @@ __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
     for (int i = 0; i < QPB; ++i) s += sAcc[i * C + c];
-    atomicAdd(ws + (long)p.B * C + (long)b * C + c, s * (drop ? p.inv_keep : 1.f));
+    ws[((long)blockIdx.x * p.B + b) * C + c] = s * (drop ? p.inv_keep : 1.f);
+  }
+}
+__global__ void attn_onekey_finish_kernel(const AttnParams p, const float* __restrict__ ws, int C, int nblk) {
+  const long n = (long)p.B * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += ws[k * n + i];
+    const int c = (int)(i % C);
+    const long b = i / C;
+    if (p.dk) p.dk[b * p.lddk + c] = (bf16)0.f;
+    p.dv[b * p.lddv + c] = (bf16)s;
   }
 }
 bool onekey_ok(const AttnParams& p) {
@@ -1145,13 +1157,12 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   if (!p.q && !onekey_ok(p)) return DM_ERR_ARG;  // the q-less form exists only on the one-token path
   if (onekey_ok(p)) {
     const int C = p.H * p.hd, QPB = 256 / (C >> 3);
-    float* ws = p.delta;  // fp32 [2][B,1,C] reduction scratch (the caller sizes it: dm_hip.h)
-    if (hipMemsetAsync(ws, 0, (size_t)2 * p.B * C * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
+    float* ws = p.delta;  // fp32 [<=32][B][C] per-block partials (the caller sizes it: dm_hip.h)
     int gx = (p.Nq + QPB - 1) / QPB;
     if (gx > 32) gx = 32;
     hipLaunchKernelGGL(attn_onekey_bwd_kernel, dim3(gx, p.B), dim3(256), 0, st, p, ws);
     DM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_small_finish_kernel, dim3(64), dim3(256), 0, st, p, (const float*)ws, C);
+    hipLaunchKernelGGL(attn_onekey_finish_kernel, dim3(64), dim3(256), 0, st, p, (const float*)ws, C, gx);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }

@@ -311,7 +311,8 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     dk = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dk is None else dk
     dv = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dv is None else dv
     # scratch: rowsum(dO*O) [B,heads,Nq]; the few-token path reuses it as the [2,B,Nk,C] fp32 dK/dV reduction
-    delta = torch.empty(max(B * heads * Nq, 2 * B * Nk * Cc), dtype=torch.float32, device=q.device)
+    delta = torch.empty(max(B * heads * Nq, 2 * B * Nk * Cc, 32 * B * Cc if Nk == 1 else 0), dtype=torch.float32,
+                        device=q.device)
     a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
     a.d_o, a.lddo = _p(d_o), _act(d_o, "d_o")
     a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
@@ -340,7 +341,7 @@ def attn_onekey_bwd(v, o, d_o, heads, *, drop_p=0.0, drop_seed=0):
     B, Nk, Cc = v.shape
     Nq = o.shape[1]
     dv = torch.empty((B, 1, Cc), dtype=BF16, device=v.device)
-    delta = torch.empty(2 * B * Cc, dtype=torch.float32, device=v.device)
+    delta = torch.empty(32 * B * Cc, dtype=torch.float32, device=v.device)   # per-block partials of dV (dm_hip.h)
     a = AttnArgs()
     a.v, a.ldv, a.o, a.ldo = _p(v), _act(v, "v"), _p(o), _act(o, "o")
     a.d_o, a.lddo, a.dv, a.lddv, a.delta = _p(d_o), _act(d_o, "d_o"), _p(dv), Cc, _p(delta)

@@ -140,7 +140,8 @@ typedef struct dm_attn_args {
   float* lse;                     /* [B, heads, Nq] fp32 log-sum-exp (natural log of sum exp(scale*s)) */
   const void* d_o; long lddo;     /* backward only */
   void* dq; long lddq; void* dk; long lddk; void* dv; long lddv;
-  float* delta;                   /* fp32 scratch (backward): max(B*heads*Nq, 2*B*Nk*heads*hd) floats */
+  float* delta;                   /* fp32 scratch (backward): max(B*heads*Nq, 2*B*Nk*heads*hd) floats;
+                                     with Nk == 1: 32*B*heads*hd floats (per-block partial sums of dV) */
   int B, heads, Nq, Nk, hd;
   float scale;                    /* 1/sqrt(hd) */
   float drop_p; unsigned long long drop_seed;
