@@ -417,7 +417,7 @@ def main():
                            "launches_timed": len(probe["pairs"]) if probe else 0,
                            "timed_where": "inside the timed training steps (HIP events around each launch)",
                            "isolated_back_to_back_us": iso_sec * 1e6}
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
     if world > 1:
