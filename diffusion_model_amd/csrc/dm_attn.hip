@@ -826,6 +826,21 @@ __device__ __forceinline__ float wide_sum8(float s) {
   s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
   return s;
 }
+// v[u] = this lane's partial sum for item u (8 items, 8 lanes per row): returns the full sum of item `part`
+// (7 shuffles for 8 items instead of 3 per item).
+__device__ __forceinline__ float wide_transpose_sum8(const float (&v)[8], int part) {
+  float w[4], x[2];
+  const bool h4 = part & 4, h2 = part & 2, h1 = part & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (h4 ? v[4 + i] : v[i]) + __shfl_xor(h4 ? v[i] : v[4 + i], 4, 64);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) x[i] = (h2 ? w[2 + i] : w[i]) + __shfl_xor(h2 ? w[i] : w[2 + i], 2, 64);
+  return (h1 ? x[1] : x[0]) + __shfl_xor(h1 ? x[0] : x[1], 1, 64);
+}
+__device__ __forceinline__ float wide_max8(float s) {
+  s = fmaxf(s, __shfl_xor(s, 1, 64)); s = fmaxf(s, __shfl_xor(s, 2, 64)); s = fmaxf(s, __shfl_xor(s, 4, 64));
+  return s;
+}
 template <int HD>
 __device__ __forceinline__ void wide_load_row(const bf16* base, bool ok, float scale, float (&f)[HD / 8]) {
 #pragma unroll
@@ -867,23 +882,40 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) 
     wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
     __syncthreads();
     const int kn = min(32, p.Nk - k0);
-    for (int j = 0; j < kn; ++j) {
-      const bf16* kr = sK + j * HD + part * DPT;
-      const bf16* vr = sV + j * HD + part * DPT;
-      float sc = 0.f;
+    // eight keys per round: every lane adds its slice of the eight dot products, a transposing reduction leaves lane
+    // `part` with the score of key j0 + part, so exp / dropout run once per key (not once per lane), and the eight
+    // probabilities go back out as broadcasts for the P.V update.  l is kept as per-lane partial sums.
+    for (int j0 = 0; j0 < kn; j0 += 8) {
+      float ps[8];
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) sc += qf[d] * (float)kr[d];
-      sc = wide_sum8(sc);
-      const float mn = fmaxf(m, sc);
+      for (int u = 0; u < 8; ++u) {
+        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
+        float t = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) t += qf[d] * (float)kr[d];
+        ps[u] = t;
+      }
+      const int key = k0 + j0 + part;
+      const float st = wide_transpose_sum8(ps, part);   // every lane takes part in the shuffles
+      const float sc = key < p.Nk ? st : -INFINITY;
+      const float mn = fmaxf(m, wide_max8(sc));
       const float alpha = __expf(m - mn), pj = __expf(sc - mn);
       l = l * alpha + pj;
       float pd = pj;
-      if (p.thresh) pd = dm_keep16(dm_drop_bits(rs, (uint32_t)(k0 + j) >> 1), (uint32_t)(k0 + j), p.thresh) ? pj * p.inv_keep : 0.f;
+      if (p.thresh) pd = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? pj * p.inv_keep : 0.f;
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) acc[d] = acc[d] * alpha + pd * (float)vr[d];
+      for (int d = 0; d < DPT; ++d) acc[d] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float pu = __shfl(pd, (tid & 56) | u, 64);
+        const bf16* vr = sV + (j0 + u) * HD + part * DPT;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) acc[d] += pu * (float)vr[d];
+      }
       m = mn;
     }
   }
+  l = wide_sum8(l);
   if (q_ok) {
     wide_store_row<HD>(p.o + ((long)b * p.Nq + q) * p.ldo + hoff + part * DPT, acc, 1.f / l);
     if (part == 0) p.lse[(long)bh * p.Nq + q] = m + __logf(l);
@@ -913,19 +945,30 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p
     wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
     __syncthreads();
     const int kn = min(32, p.Nk - k0);
-    for (int j = 0; j < kn; ++j) {
-      const bf16* kr = sK + j * HD + part * DPT;
-      const bf16* vr = sV + j * HD + part * DPT;
-      float sc = 0.f, dp = 0.f;
+    for (int j0 = 0; j0 < kn; j0 += 8) {  // eight keys per round, as in the forward
+      float ps[8], pp[8];
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) { sc += qf[d] * (float)kr[d]; dp += df[d] * (float)vr[d]; }
-      sc = wide_sum8(sc); dp = wide_sum8(dp);
-      const float pj = __expf(sc - L);
+      for (int u = 0; u < 8; ++u) {
+        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
+        const bf16* vr = sV + (j0 + u) * HD + part * DPT;
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) { t += qf[d] * (float)kr[d]; t2 += df[d] * (float)vr[d]; }
+        ps[u] = t; pp[u] = t2;
+      }
+      const int key = k0 + j0 + part;
+      const float sc = wide_transpose_sum8(ps, part), dp = wide_transpose_sum8(pp, part);
+      const float pj = key < p.Nk ? __expf(sc - L) : 0.f;
       float zf = 1.f;
-      if (p.thresh) zf = dm_keep16(dm_drop_bits(rs, (uint32_t)(k0 + j) >> 1), (uint32_t)(k0 + j), p.thresh) ? p.inv_keep : 0.f;
+      if (p.thresh) zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
       const float ds = pj * (zf * dp - dl);
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) acc[d] += ds * (float)kr[d];
+      for (int u = 0; u < 8; ++u) {
+        const float du = __shfl(ds, (tid & 56) | u, 64);
+        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) acc[d] += du * (float)kr[d];
+      }
     }
   }
   if (q_ok) wide_store_row<HD>(p.dq + ((long)b * p.Nq + q) * p.lddq + hoff + part * DPT, acc, p.scale);
@@ -957,22 +1000,34 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams 
     }
     __syncthreads();
     const int qn = min(32, p.Nq - q0);
-    for (int i = 0; i < qn; ++i) {
-      const bf16* qr = sQ + i * HD + part * DPT;
-      const bf16* dr = sD + i * HD + part * DPT;
-      float sc = 0.f, dp = 0.f;
+    for (int i0 = 0; i0 < qn; i0 += 8) {  // eight queries per round: lane `part` finishes query i0 + part
+      float ps[8], pp[8];
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) { sc += kf[d] * (float)qr[d]; dp += vf[d] * (float)dr[d]; }
-      sc = wide_sum8(sc); dp = wide_sum8(dp);
-      const float pj = __expf(sc - sL[i]);
+      for (int u = 0; u < 8; ++u) {
+        const bf16* qr = sQ + (i0 + u) * HD + part * DPT;
+        const bf16* dr = sD + (i0 + u) * HD + part * DPT;
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) { t += kf[d] * (float)qr[d]; t2 += vf[d] * (float)dr[d]; }
+        ps[u] = t; pp[u] = t2;
+      }
+      const int qi = q0 + i0 + part;
+      const float sc = wide_transpose_sum8(ps, part), dp = wide_transpose_sum8(pp, part);
+      const float pj = qi < p.Nq ? __expf(sc - sL[i0 + part]) : 0.f;
       float zf = 1.f;
       if (p.thresh) {
-        const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q0 + i));
+        const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi));
         zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
       }
-      const float ds = pj * (zf * dp - sDl[i]), pz = pj * zf;
+      const float ds = pj * (zf * dp - sDl[i0 + part]), pz = pj * zf;
 #pragma unroll
-      for (int d = 0; d < DPT; ++d) { dk[d] += ds * (float)qr[d]; dv[d] += pz * (float)dr[d]; }
+      for (int u = 0; u < 8; ++u) {
+        const float du = __shfl(ds, (tid & 56) | u, 64), zu = __shfl(pz, (tid & 56) | u, 64);
+        const bf16* qr = sQ + (i0 + u) * HD + part * DPT;
+        const bf16* dr = sD + (i0 + u) * HD + part * DPT;
+#pragma unroll
+        for (int d = 0; d < DPT; ++d) { dk[d] += du * (float)qr[d]; dv[d] += zu * (float)dr[d]; }
+      }
     }
   }
   if (k_ok) {
