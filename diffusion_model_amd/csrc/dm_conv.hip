@@ -25,7 +25,10 @@
 
 namespace {
 
-enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UP = 2, MODE_ZI = 3, MODE_GEMM = 4 };
+// MODE_Q8: stride-1 conv on 8x8 images, FOUR images per workgroup tile (the latent model's innermost stage): each image
+// gets its own 10x10 halo patch inside a 20x20 LDS patch and one wave; the weight stages are shared by 256 pixels
+// instead of 64 (a quarter of the L2 -> LDS weight traffic, four m-tiles per weight fragment).
+enum { MODE_S1 = 0, MODE_S2 = 1, MODE_UP = 2, MODE_ZI = 3, MODE_GEMM = 4, MODE_Q8 = 5 };
 
 struct ConvParams {
   const bf16* x; long ldx;       // input pixel stride (elements)
@@ -70,6 +73,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
           pix = m0 + q;
           ok = pix < p.M;
           bb = ok ? (int)(pix / p.rows_per_batch) : 0;
+        } else if constexpr (MODE == MODE_Q8) {
+          bb = b + (q >> 6);                           // image of the quad
+          ok = bb < p.B;
+          pix = (long)bb * 64 + (q & 63);
+          if (!ok) bb = 0;
         } else {
           const int r = q / TW, c = q % TW;
           ok = (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile may overhang the image
@@ -137,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
     if (p.pool2) {
-      if constexpr (MODE != MODE_GEMM && TW == 16 && (MT % 2) == 0) {
+      if constexpr (MODE != MODE_GEMM && MODE != MODE_Q8 && TW == 16 && (MT % 2) == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt += 2) {
           f32x4 v = acc[mt][nt] + acc[mt + 1][nt];
@@ -165,6 +173,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         pix = m0 + q;
         if (pix >= p.M) continue;
         bb = (int)(pix / p.rows_per_batch);
+      } else if constexpr (MODE == MODE_Q8) {
+        bb = b + (q >> 6);
+        if (bb >= p.B) continue;
+        pix = (long)bb * 64 + (q & 63);
       } else {
         const int r = q / TW, c = q % TW;
         if (h0 + r >= p.Ho || w0 + c >= p.Wo) continue;  // tile overhangs the image
@@ -206,8 +218,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   constexpr int TAPS = (MODE == MODE_GEMM) ? 1 : 9;
-  constexpr int PH = (MODE == MODE_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
-  constexpr int PW = (MODE == MODE_GEMM) ? TW : ((S == 1) ? TW + 2 : 2 * TW + 1);
+  constexpr int PH = (MODE == MODE_GEMM) ? TH : (MODE == MODE_Q8) ? 20 : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int PW = (MODE == MODE_GEMM) ? TW : (MODE == MODE_Q8) ? 20 : ((S == 1) ? TW + 2 : 2 * TW + 1);
   constexpr int MT = TH * TW / 64;  // m-tiles (16 pixels) per wave
   constexpr int A_BYTES = ((PH * PITCH * STRIDE + 15) / 16) * 16;
   constexpr int KSPS = (NT <= 4) ? 2 : 1;       // k-steps (of 32) per B stage
@@ -227,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   if constexpr (MODE == MODE_GEMM) {
     m0 = (long)blockIdx.x * (TH * TW);
     b = 0; h0 = 0; w0 = 0;
+  } else if constexpr (MODE == MODE_Q8) {
+    b = blockIdx.x * 4; h0 = 0; w0 = 0;  // first image of the quad
   } else {
     int tile = blockIdx.x;
     const int tw_i = tile % p.tiles_w; tile /= p.tiles_w;
@@ -241,7 +255,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int q = (wave * MT + mt) * 16 + (lane & 15);
-    const int r = q / TW, c = q % TW;
+    int r = q / TW, c = q % TW;
+    if constexpr (MODE == MODE_Q8) {  // image q >> 6 of the quad sits at patch origin (10 * (i >> 1), 10 * (i & 1))
+      r = ((q >> 6) >> 1) * 10 + ((q & 63) >> 3);
+      c = ((q >> 6) & 1) * 10 + (q & 7);
+    }
     aoff[mt] = ((S * r) * PITCH + S * c) * STRIDE + (lane >> 4) * 16;
   }
 
@@ -278,6 +296,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         const long m = m0 + pp;
         valid = valid && (m < p.M) && (ch < p.Cin);
         src = m * p.ldx + ch;
+      } else if constexpr (MODE == MODE_Q8) {
+        const int img = b + (pr / 10) * 2 + (pc / 10), lr = pr % 10 - 1, lc = pc % 10 - 1;
+        valid = valid && (img < p.B) && (lr >= 0) && (lr < 8) && (lc >= 0) && (lc < 8);
+        src = ((long)img * 64 + lr * 8 + lc) * p.ldx + ch;
       } else {
         const int vh = vh0 + pr, vw = vw0 + pc;
         int sh = vh, sw = vw;
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
 template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
 int launch_conv(const ConvParams& p, hipStream_t st) {
-  constexpr int PH = (MODE == MODE_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
+  constexpr int PH = (MODE == MODE_GEMM) ? TH : (MODE == MODE_Q8) ? 20 : ((S == 1) ? TH + 2 : 2 * TH + 1);
   constexpr int A_BYTES = ((PH * PITCH * STRIDE + 15) / 16) * 16;
   constexpr int KSPS = (NT <= 4) ? 2 : 1;
   constexpr int LDS = A_BYTES + 2 * KSPS * NT * 1024;
@@ -408,6 +430,7 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   }
   dim3 grid;
   if (MODE == MODE_GEMM) grid = dim3((unsigned)((p.M + TH * TW - 1) / (TH * TW)), (unsigned)(p.Cout / (16 * NT)));
+  else if (MODE == MODE_Q8) grid = dim3((unsigned)((p.B + 3) / 4), (unsigned)(p.Cout / (16 * NT)));
   else grid = dim3((unsigned)(p.B * p.tiles_h * p.tiles_w), (unsigned)(p.Cout / (16 * NT)));
   hipLaunchKernelGGL(k, grid, dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
@@ -671,6 +694,13 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
     if (wide) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);            \
     return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
   } while (0)
+  if (mode == 0 && a->H == 8 && a->W == 8 && a->B >= 4 && !p.pool2) {
+    // 8x8 images (the latent model's innermost stage: 4096 pixels against K*N up to 9216 x 1024): four images per
+    // workgroup; 32-cout workgroups when the 64-cout grid would leave CUs idle
+    const int quads = (a->B + 3) / 4;
+    if ((long)quads * (a->Cout / 64) >= 256) return launch_conv<16, 16, 1, 20, 160, 4, MODE_Q8>(p, st);
+    return launch_conv<16, 16, 1, 20, 160, 2, MODE_Q8>(p, st);
+  }
   if (mode == 1) DM_GO(8, 8, 2, 24, 144, MODE_S2);
   // tile shape = the one that covers the image with the least padded area (edge tiles are masked);
   // ties go to the larger tile (fewer halo bytes per pixel). pool2 needs whole row pairs per wave: 16x16.

@@ -43,7 +43,9 @@ def K():
 
 # ------------------------------------------------------------------ conv forward
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 32, 48, 128, 128), (2, 24, 24, 128, 256),
-                                            (2, 8, 8, 64, 128), (1, 96, 96, 64, 64), (2, 12, 12, 64, 64), (1, 20, 36, 64, 128)])
+                                            (2, 8, 8, 64, 128), (1, 96, 96, 64, 64), (2, 12, 12, 64, 64), (1, 20, 36, 64, 128),
+                                            # 8x8 images, B >= 4: four images per workgroup tile (mode 0), ragged last quad
+                                            (8, 8, 8, 128, 256), (5, 8, 8, 64, 64), (64, 8, 8, 64, 1024)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_conv3x3_fwd(K, B, H, W, Cin, Cout, mode):
     if mode == 1 and (H % 2 or W % 2):
@@ -80,7 +82,8 @@ def test_conv3x3_silu_in_f32_out_and_slices(K):
 
 
 # ------------------------------------------------------------------ conv data-gradient
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 48, 48, 128, 64), (1, 24, 24, 256, 128), (2, 12, 12, 64, 64), (1, 20, 36, 128, 64)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 128), (1, 48, 48, 128, 64), (1, 24, 24, 256, 128), (2, 12, 12, 64, 64), (1, 20, 36, 128, 64),
+                                            (6, 8, 8, 128, 64)])
 def test_conv3x3_dgrad_s1(K, B, H, W, Cin, Cout):
     x = rnd(B, Cin, H, W, seed=1).requires_grad_()
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
