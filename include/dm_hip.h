@@ -116,7 +116,8 @@ int dm_wgrad(const dm_wgrad_args* args, dm_stream_t stream);
 
 /* ------------------------------------------------------------------ GroupNorm + SiLU */
 long dm_gn_workspace_bytes(int B, int HW, int C, int G);
-/* y = act(GroupNorm(x + chan_add)) ; stats[b][g] = {mean, rstd} saved for the backward.
+/* y = act(GroupNorm(x + chan_add)) ; stats[b][g] = {mean, rstd} saved for the backward.  C <= 1024, a power-of-two
+ * multiple of 8 (C/8 divides 256), G <= 64, C/G a multiple of 8.
  * Replaces nn.GroupNorm(8,C) + nn.SiLU (+ the time-embedding add) (unet.py:77-78,94,101-102,106). */
 int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
                    void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
@@ -142,7 +143,8 @@ typedef struct dm_attn_args {
   void* dq; long lddq; void* dk; long lddk; void* dv; long lddv;
   float* delta;                   /* fp32 scratch (backward): max(B*heads*Nq, 2*B*Nk*heads*hd) floats;
                                      with Nk == 1: 32*B*heads*hd floats (per-block partial sums of dV) */
-  int B, heads, Nq, Nk, hd;
+  int B, heads, Nq, Nk, hd;       /* hd in {8,16,32} (MFMA flash / few-token kernels) or {64,128} (latent-model widths,
+                                     utils.py:145-156: fp32 VALU kernels) */
   float scale;                    /* 1/sqrt(hd) */
   float drop_p; unsigned long long drop_seed;
 } dm_attn_args;
