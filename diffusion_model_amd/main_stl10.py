@@ -162,12 +162,15 @@ def generate_fixed_seed_class_grid(model, scheduler, cfg_scale: float = CFG_SCAL
     z = torch.cat([torch.randn(1, 3, size, size, generator=torch.Generator().manual_seed(base_seed + i))
                    for i in range(len(label_ids))]).to(device)
     labels = torch.tensor(label_ids, device=device, dtype=torch.long)
-    gen = torch.Generator(device=device).manual_seed(base_seed)
+    import torch.distributed as dist
+    from .sampler import sample_sharded
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    gen = torch.Generator(device=device).manual_seed(base_seed + rank)
     sampler = CFGSampler(model, scheduler, utils.CONTEXT_TABLE.to(device), UNCOND_ID)
     model.eval()
-    with torch.no_grad():
-        return sampler.sample(z, labels, guidance_scale=cfg_scale, eta=eta, num_time_steps=num_time_steps,
-                              generator=gen)
+    with torch.no_grad():  # under torchrun: every rank samples its shard of the labels, one gather at the end
+        return sample_sharded(sampler.sample, z, labels, guidance_scale=cfg_scale, eta=eta,
+                              num_time_steps=num_time_steps, generator=gen)
 
 
 def inference(checkpoint_path, label: Optional[int] = None, guidance_scale: float = CFG_SCALE,

@@ -217,3 +217,32 @@ class CFGSampler:
             v_u, v_c = (v[:S], v[S:]) if guided else (v, v)
             z, m_prev = K.cfg_dpmpp2m_step(z, v_u, v_c, m_prev, coefs[i])
         return z
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n samples for ``rank`` of ``world`` (sizes differ by at most one)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sample_sharded(sample_fn, z: torch.Tensor, labels: torch.Tensor, *, group=None, **kw) -> torch.Tensor:
+    """Data-parallel sampling (config C4 = 704 images over the ranks): every rank runs
+    ``sample_fn(z[lo:hi], labels[lo:hi], **kw)`` on its own contiguous shard -- NO collective inside the step loop --
+    and ONE all-gather at the end returns the full batch, in the caller's order, on every rank.  ``sample_fn`` is e.g.
+    ``CFGSampler(...).sample`` or ``.sample_dpm`` bound with its arguments; ``z`` / ``labels`` are the same on all ranks
+    (seeded start noise), the per-step ancestral noise is rank-local."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sample_fn(z, labels, **kw)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = z.shape[0]
+    lo, hi = shard_bounds(n, rank, world)
+    out = sample_fn(z[lo:hi], labels[lo:hi], **kw) if hi > lo else z[:0].clone()
+    width = (n + world - 1) // world                       # all_gather wants equal shapes: pad the short shards
+    pad = torch.zeros((width, *z.shape[1:]), dtype=out.dtype if hi > lo else z.dtype, device=z.device)
+    pad[: hi - lo] = out
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    sizes = [shard_bounds(n, r, world) for r in range(world)]
+    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)])

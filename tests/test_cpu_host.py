@@ -187,3 +187,50 @@ def test_dp_gradient_buckets_gloo_world2():
         assert p.exitcode == 0
     for rank, ok, err in res:
         assert ok, f"rank {rank}: bucketed all-reduce differs from the gathered sum by {err}"
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from diffusion_model_amd.sampler import sample_sharded, shard_bounds
+        g = torch.Generator().manual_seed(3)                      # same start noise / labels on every rank
+        z, labels = torch.randn(5, 3, 4, 4, generator=g), torch.arange(5)
+        seen = []
+
+        def fn(zs, ls, scale=1.0):                                # stands in for CFGSampler.sample on the shard
+            seen.append(zs.shape[0])
+            return zs * scale + ls.view(-1, 1, 1, 1).float()
+
+        out = sample_sharded(fn, z, labels, scale=2.0)
+        want = z * 2.0 + labels.view(-1, 1, 1, 1).float()
+        lo, hi = shard_bounds(5, rank, world)
+        q.put((rank, bool(torch.equal(out, want)), seen == [hi - lo], (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_gloo_world2():
+    """SURVEY 8e, sampling: contiguous shards per rank, no collective in the loop, one final gather (ragged: 5 over 2)."""
+    import torch.multiprocessing as mp
+    from diffusion_model_amd.sampler import sample_sharded, shard_bounds
+    assert [shard_bounds(704, r, 8) for r in (0, 7)] == [(0, 88), (616, 704)]
+    assert [shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    z = torch.ones(3, 1, 2, 2)
+    assert torch.equal(sample_sharded(lambda a, b: a + 1, z, torch.zeros(3)), z + 1)   # no process group: pass-through
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [(0, 3), (3, 5)]
+    for rank, same, one_call, _ in res:
+        assert same and one_call, f"rank {rank}: gathered batch differs from the single-process result"
