@@ -239,6 +239,19 @@ def main():
     gen_unet_init("stl10_init", stl, 2, 96, "clip")
     gen_unet_init("stl10_init_noctx", stl, 2, 48, None)
     gen_unet_init("mnist_init", mn, 4, 32, "labels")
+    gen_ldm()
+
+
+def gen_ldm():
+    """The reference's latent-diffusion configuration (utils.py:145-156) through the real reference UNET: closed-form
+    weights at 16x16 (pins the oracle: heads of 64 / 128 dimensions, GroupNorm groups of 128 channels) and the
+    reference-default init at 32x32 latents with and without context (pins the HIP path)."""
+    ldm = dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
+               output_channels=4, context_dim=512, dropout_prob=0.0, time_steps=1000)
+    gen_unet("ldm_small", ldm, 1, 16, "clip")
+    gen_unet("ldm_small_noctx", ldm, 1, 16, None)
+    gen_unet_init("ldm_init", ldm, 2, 32, "clip")
+    gen_unet_init("ldm_init_noctx", ldm, 2, 16, None)
 
 
 if __name__ == "__main__":

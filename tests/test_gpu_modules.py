@@ -118,8 +118,11 @@ def test_full_unet_vs_reference(tag, spec_kw):
     # asserted on realistic weights in test_full_unet_realistic_init_vs_reference below.
 
 
+LDM_KW = dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
+              output_channels=4, context_dim=512, dropout_prob=0.0)   # reference utils.py:145-156
 INIT_CASES = [("stl10_init", STL, "clip"), ("stl10_init_noctx", STL, None),
-              ("mnist_init", dict(Attentions=[False] * 6, dropout_prob=0.0), "labels")]
+              ("mnist_init", dict(Attentions=[False] * 6, dropout_prob=0.0), "labels"),
+              ("ldm_init", LDM_KW, "clip"), ("ldm_init_noctx", LDM_KW, None)]
 
 
 @pytest.mark.parametrize("tag,spec_kw,ctx_mode", INIT_CASES)

@@ -132,6 +132,11 @@ def test_cross_attention(tag, C):
     ("stl10_clip", dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0), 96),
     ("stl10_noctx", dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0), 96),
     ("mnist", dict(Attentions=[False] * 6, dropout_prob=0.0), 32),
+    # the reference's latent-diffusion configuration (utils.py:145-156): heads of 64 / 128 dimensions
+    ("ldm_small", dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
+                       output_channels=4, context_dim=512, dropout_prob=0.0), 16),
+    ("ldm_small_noctx", dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False],
+                             input_channels=4, output_channels=4, context_dim=512, dropout_prob=0.0), 16),
 ])
 def test_full_unet(tag, spec_kw, hw):
     g = load_golden(f"unet_{tag}")
