@@ -167,7 +167,13 @@ class Trainer:
         if self.low_t_weight is None:
             w = torch.full((B,), 1.0 / (B * chw), dtype=torch.float32, device=x.device)
         else:
-            w = torch.exp(-self.low_t_weight * t.float()) / (B * chw)
+            # exp(-k t) / (B chw) for every timestep once (the same elementwise ops the per-batch statement ran, so the
+            # rows are bit-identical): one gather per micro-batch instead of four small kernels
+            key = (B * chw, self.low_t_weight, x.device)
+            if getattr(self, "_wtab_key", None) != key:
+                steps = torch.arange(self.scheduler.alpha_t.numel(), device=x.device)
+                self._wtab, self._wtab_key = torch.exp(-self.low_t_weight * steps.float()) / (B * chw), key
+            w = self._wtab[t]
         loss, dout = K.mse_loss_fwd_bwd(y, tgt, w.contiguous(), grad_scale=1.0 / self.accum)
         if check_finite and not bool(torch.isfinite(loss).all().item()):
             return loss  # reference: "continue" -- no backward, no accumulation-counter change
