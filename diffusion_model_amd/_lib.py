@@ -80,6 +80,7 @@ _SIGS = {
     "dm_silu_bwd_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "dm_colsum_bf16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dm_batchsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dm_batchsum2_cast_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dm_qsample_vtarget": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dm_mse_workspace_bytes": (c_long, [c_int]),
     "dm_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_long,

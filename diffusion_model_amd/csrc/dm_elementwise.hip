@@ -142,6 +142,31 @@ __global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__
   if (tid < 64 && c < C) out[c] += red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
 }
 
+// out1[c] += sum_b in[b][c]; out2[c] += the same sum (optional); cast[b][c] = bf16(in[b][c]) (optional): the three
+// consumers of a ResBlock's per-(sample, channel) gradient sums in one pass
+__global__ __launch_bounds__(256) void batchsum2_cast_kernel(const float* __restrict__ in, float* __restrict__ out1,
+                                                             float* __restrict__ out2, bf16* __restrict__ cast, int B,
+                                                             int C) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, c = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
+  float a = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = rl; b < B; b += 4) {
+      const float v = in[(long)b * C + c];
+      a += v;
+      if (cast) cast[(long)b * C + c] = (bf16)v;
+    }
+  }
+  red[tid] = a;
+  __syncthreads();
+  if (tid < 64 && c < C) {
+    const float s = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+    out1[c] += s;
+    if (out2) out2[c] += s;
+  }
+}
+
 // ---------------------------------------------------------------- diffusion math (fp32 NCHW)
 __global__ void qsample_kernel(const float* __restrict__ x, const float* __restrict__ e,
                                const float* __restrict__ abar_t, float* __restrict__ xt, float* __restrict__ v,
@@ -386,6 +411,15 @@ extern "C" int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, i
   DM_REQUIRE(C / 8 <= 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(nbatch), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out,
                      rows_per_batch, C, accumulate);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_batchsum2_cast_f32(const float* in, float* out1, float* out2, void* cast_bf16, int B, int C,
+                                     dm_stream_t stream) {
+  DM_REQUIRE(in && out1 && B > 0 && C > 0);
+  hipLaunchKernelGGL(batchsum2_cast_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out1, out2,
+                     (bf16*)cast_bf16, B, C);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -421,6 +421,15 @@ def batchsum(inp, out):
     check(_lib.lib().dm_batchsum_f32(_p(_f32(inp, "in")), _p(_f32(out, "out")), B, Cc, _stream()), "dm_batchsum_f32")
 
 
+def batchsum2_cast(inp, out1, out2=None, want_bf16=True):
+    """out1 += sum_b inp[b]; out2 += the same (optional); returns inp as bf16 (optional) -- one launch."""
+    B, Cc = inp.shape
+    cast = torch.empty((B, Cc), dtype=BF16, device=inp.device) if want_bf16 else None
+    check(_lib.lib().dm_batchsum2_cast_f32(_p(_f32(inp.contiguous(), "in")), _p(_f32(out1, "out1")),
+                                           _p(_f32(out2, "out2")), _p(cast), B, Cc, _stream()), "dm_batchsum2_cast_f32")
+    return cast
+
+
 # --------------------------------------------------------------------------- diffusion math
 def qsample_vtarget(x, e, abar_t):
     B = x.shape[0]

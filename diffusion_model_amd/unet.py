@@ -254,9 +254,7 @@ class ResBlock(HipModule):
         dtp = torch.zeros((B, self.cout), dtype=torch.float32, device=x.device)
         dh = K.gn_silu_bwd(h, d_g2, self.norm2.weight.detach(), self.norm2.bias.detach(), st2, self.groups,
                            g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed, colsum_out=dtp)
-        K.batchsum(dtp, g.of(self.conv1.bias))
-        K.batchsum(dtp, g.of(lin.bias))
-        dtp16 = K.to_bf16(dtp)
+        dtp16 = K.batchsum2_cast(dtp, g.of(self.conv1.bias), g.of(lin.bias))   # both bias gradients + the bf16 operand
         K.wgrad_side(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
         d_this = torch.empty((B, temb.shape[-1]), dtype=torch.float32, device=x.device)
         K.gemm(dtp16, PW.of(lin).bwd, temb.shape[-1], out_f32=d_this)

@@ -178,6 +178,10 @@ int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, int rows_per
                    dm_stream_t stream);
 /* out[c] += sum_b in[b][c]. */
 int dm_batchsum_f32(const float* in, float* out, int B, int C, dm_stream_t stream);
+/* The same sum added to out1 and (optional) out2, plus an optional bf16 copy of `in` ([B][C]): the bias gradients of
+ * conv1 and of the time projection and the bf16 operand of the projection's weight gradient (unet.py:87-90,101-102)
+ * from a ResBlock's per-(sample, channel) sums in one pass. */
+int dm_batchsum2_cast_f32(const float* in, float* out1, float* out2, void* cast_bf16, int B, int C, dm_stream_t stream);
 
 /* ------------------------------------------------------------------ diffusion math (fp32) */
 /* x_t = sqrt(a) x + sqrt(1-a) e ; v = sqrt(a) e - sqrt(1-a) x   (main_stl10.py:456-465). */

@@ -414,3 +414,17 @@ def test_gn_silu_bwd_fused_column_sums():
         dx = K.gn_silu_bwd(x, dy, gam, bet, stats, G, dg, db, drop_p=0.1, drop_seed=7, colsum_out=cs)
         ref = dx.float().sum(dim=(1, 2)) + 0.5
         assert torch.allclose(cs, ref, rtol=1e-4, atol=1e-3), float((cs - ref).abs().max())
+
+
+def test_batchsum2_cast(K):
+    """One pass for a ResBlock's per-(sample, channel) sums: both bias gradients (+=) and the bf16 copy."""
+    for B, C in ((64, 64), (5, 1024), (3, 72)):
+        x = rnd(B, C, seed=B + C)
+        o1, o2 = torch.full((C,), 0.25, device=dev()), torch.full((C,), -1.0, device=dev())
+        c16 = K.batchsum2_cast(x, o1, o2)
+        assert_close(o1, x.sum(0) + 0.25, 1e-5, "out1")
+        assert_close(o2, x.sum(0) - 1.0, 1e-5, "out2")
+        assert torch.equal(c16, x.to(torch.bfloat16))
+        o3 = torch.zeros(C, device=dev())
+        assert K.batchsum2_cast(x, o3, None, want_bf16=False) is None
+        assert_close(o3, x.sum(0), 1e-5, "out1 alone")
