@@ -73,6 +73,18 @@ class PW:
             self._kb = key
         return self._bwd
 
+    def bias_pad(self, npad: int):
+        """The bias zero-padded to ``npad`` entries (the output conv's 16-wide channel tile), rebuilt only when the bias
+        changed (same staleness rule as the packed weights)."""
+        b = self.c.bias
+        if b is None:
+            return None
+        key = (b.data_ptr(), b._version, _EPOCH[0], npad)
+        if getattr(self, "_kbias", None) != key:
+            self._bias = _pad_bias(self.c, npad)
+            self._kbias = key
+        return self._bias
+
 
 def repack_all(model: nn.Module) -> None:
     """Rebuild every packed shadow the model has used so far in ONE launch (dm_pack_weights_batch) and mark
@@ -642,7 +654,7 @@ class UNET(HipModule):
         a2 = K.conv3x3(a1, PW.of(self.late_conv2).fwd, Cc // 2, bias=_b(self.late_conv2), act_silu_in=True)
         npad = (self.cout_img + 15) // 16 * 16
         of = torch.empty((Bc, Hc, Wc, npad), dtype=torch.float32, device=dev_)
-        K.gemm(a2.view(Bc, Hc * Wc, Cc // 2), PW.of(self.output_conv).fwd, npad, bias=_pad_bias(self.output_conv, npad),
+        K.gemm(a2.view(Bc, Hc * Wc, Cc // 2), PW.of(self.output_conv).fwd, npad, bias=PW.of(self.output_conv).bias_pad(npad),
                act_silu_in=True, out_f32=of.view(Bc, Hc * Wc, npad), n_valid=self.cout_img)
         y = K.nhwc_to_nchw(of, self.cout_img)
         return y, (x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2)
