@@ -199,19 +199,37 @@ def cpu_baseline():
                       f"after 1 warm-up; torch {torch.__version__} CPU, {threads} threads"}
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N rank processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) from THIS process, which never touches a GPU itself, and return their exit code.  Rank 0
+    of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))   # before anything initialises a GPU in this process
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU is the contract")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     from diffusion_model_amd.ema import ModelEmaV2
     from diffusion_model_amd.sampler import CFGSampler
@@ -382,7 +400,10 @@ def main():
         return
     out = {
         "metric": "train img/s (node) STL10 96x96 UNet B=64/GPU", "value": value, "unit": "img/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
+        "collective": "RCCL all-reduce (torch.distributed nccl backend), 6 buckets, only on accumulation boundaries"
+                      if world > 1 else None,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic", "final_loss": final_loss,
         "config": {"workload": "configs[1]: main_stl10 UNet v-pred train step 96x96x3, B=64/GPU bf16, AdamW+EMA+clip, "

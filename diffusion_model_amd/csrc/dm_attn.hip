@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) 
   wide_load_row<HD>(p.q + ((long)b * p.Nq + q) * p.ldq + hoff + part * DPT, q_ok, p.scale, qf);
 #pragma unroll
   for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m = NEG, l = 0.f;  // finite sentinel: the library is built with -ffast-math (no infinities)
   const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) 
       }
       const int key = k0 + j0 + part;
       const float st = wide_transpose_sum8(ps, part);   // every lane takes part in the shuffles
-      const float sc = key < p.Nk ? st : -INFINITY;
+      const float sc = key < p.Nk ? st : NEG;
       const float mn = fmaxf(m, wide_max8(sc));
       const float alpha = __expf(m - mn), pj = __expf(sc - mn);
       l = l * alpha + pj;
@@ -1170,6 +1170,7 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     const int QPB = 256 / ((p.H * p.hd) >> 3);
     int gx = (p.Nq + QPB - 1) / QPB;
     if (gx > 32) gx = 32;
+    dm_set_variant("attn_onekey_fwd");
     hipLaunchKernelGGL(attn_onekey_fwd_kernel, dim3(gx, p.B), dim3(256), 0, (hipStream_t)stream, p);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -1178,6 +1179,7 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     const int C = p.H * p.hd, QB = 256 / p.H;
     const dim3 g((p.Nq + QB * SMALL_CHUNKS - 1) / (QB * SMALL_CHUNKS), p.B);
     const size_t lds = (size_t)(2 * p.Nk * C + QB * p.H * p.Nk) * sizeof(float);
+    dm_set_variant("attn_small_fwd");
     if (p.hd == 8) hipLaunchKernelGGL(attn_small_fwd_kernel<8>, g, dim3(256), lds, (hipStream_t)stream, p);
     else if (p.hd == 16) hipLaunchKernelGGL(attn_small_fwd_kernel<16>, g, dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_small_fwd_kernel<32>, g, dim3(256), lds, (hipStream_t)stream, p);
@@ -1187,6 +1189,7 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   if (p.hd >= 64) {  // wide heads (latent-model widths): fp32 VALU kernels
     DM_REQUIRE((p.ldo & 7) == 0);
     const dim3 g((p.Nq + 31) / 32, p.B * p.H);
+    dm_set_variant("attn_wide_fwd");
     if (p.hd == 64) hipLaunchKernelGGL(attn_wide_fwd_kernel<64>, g, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_wide_fwd_kernel<128>, g, dim3(256), 0, (hipStream_t)stream, p);
     DM_LAUNCH_CHECK();
@@ -1196,6 +1199,8 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   const bool edge = (p.Nk & 63) != 0;
 #define DM_FWD(DT, DROP, EDGE) hipLaunchKernelGGL((attn_fwd_kernel<DT, DROP, EDGE>), grid, dim3(256), 0, (hipStream_t)stream, p)
 #define DM_FWD2(DT, DROP) do { if (edge) DM_FWD(DT, DROP, true); else DM_FWD(DT, DROP, false); } while (0)
+  dm_set_variant(p.hd > 16 ? (p.thresh ? "attn_flash_fwd<DT=2,DROP=1>" : "attn_flash_fwd<DT=2,DROP=0>")
+                           : (p.thresh ? "attn_flash_fwd<DT=1,DROP=1>" : "attn_flash_fwd<DT=1,DROP=0>"));
   if (p.hd > 16) { if (p.thresh) DM_FWD2(2, true); else DM_FWD2(2, false); }
   else { if (p.thresh) DM_FWD2(1, true); else DM_FWD2(1, false); }
 #undef DM_FWD2
@@ -1215,6 +1220,7 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     float* ws = p.delta;  // fp32 [<=32][B][C] per-block partials (the caller sizes it: dm_hip.h)
     int gx = (p.Nq + QPB - 1) / QPB;
     if (gx > 32) gx = 32;
+    dm_set_variant("attn_onekey_bwd");
     hipLaunchKernelGGL(attn_onekey_bwd_kernel, dim3(gx, p.B), dim3(256), 0, st, p, ws);
     DM_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_onekey_finish_kernel, dim3(64), dim3(256), 0, st, p, (const float*)ws, C, gx);
@@ -1228,6 +1234,7 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     if (hipMemsetAsync(ws, 0, (size_t)2 * p.B * p.Nk * C * sizeof(float), st) != hipSuccess) return DM_ERR_LAUNCH;
     const dim3 g((p.Nq + QB * SMALL_CHUNKS - 1) / (QB * SMALL_CHUNKS), p.B);
     const size_t lds = (size_t)(2 * p.Nk * C + 2 * QB * p.H * p.Nk) * sizeof(float);
+    dm_set_variant("attn_small_bwd");
     if (p.hd == 8) hipLaunchKernelGGL(attn_small_bwd_kernel<8>, g, dim3(256), lds, st, p, ws);
     else if (p.hd == 16) hipLaunchKernelGGL(attn_small_bwd_kernel<16>, g, dim3(256), lds, st, p, ws);
     else hipLaunchKernelGGL(attn_small_bwd_kernel<32>, g, dim3(256), lds, st, p, ws);
@@ -1252,6 +1259,7 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   if (p.hd >= 64) {
     DM_REQUIRE((p.lddq & 7) == 0 && (p.lddk & 7) == 0 && (p.lddv & 7) == 0);
     const dim3 gk((p.Nk + 31) / 32, p.B * p.H), gqw((p.Nq + 31) / 32, p.B * p.H);
+    dm_set_variant("attn_wide_bwd");
     if (p.hd == 64) {
       hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<64>, gk, dim3(256), 0, st, p);
       hipLaunchKernelGGL(attn_wide_bwd_q_kernel<64>, gqw, dim3(256), 0, st, p);
@@ -1271,6 +1279,8 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     if (edge) hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP, true>), gq, dim3(256), 0, st, p);  \
     else hipLaunchKernelGGL((attn_bwd_q_kernel<DT, DROP, false>), gq, dim3(256), 0, st, p);      \
   } while (0)
+  dm_set_variant(p.hd > 16 ? (p.thresh ? "attn_flash_bwd<DT=2,DROP=1>" : "attn_flash_bwd<DT=2,DROP=0>")
+                           : (p.thresh ? "attn_flash_bwd<DT=1,DROP=1>" : "attn_flash_bwd<DT=1,DROP=0>"));
   if (p.hd > 16) { if (p.thresh) DM_BWD(2, true); else DM_BWD(2, false); }
   else { if (p.thresh) DM_BWD(1, true); else DM_BWD(1, false); }
 #undef DM_BWD

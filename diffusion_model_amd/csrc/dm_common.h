@@ -34,6 +34,14 @@ extern "C" void dm_note_hip_error(int code);  // dm_api.hip: remembered for dm_l
     if (!(cond)) return DM_ERR_ARG; \
   } while (0)
 
+// dm_api.hip: name of the kernel instantiation the calling thread launched last (dm_last_variant()).  A launcher
+// formats its name once (function-local static DmVariantName) and records the pointer per launch.
+struct DmVariantName {
+  char s[96];
+  DmVariantName(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+};
+void dm_set_variant(const char* name);
+
 static inline int dm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float dm_silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -432,6 +432,8 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   if (MODE == MODE_GEMM) grid = dim3((unsigned)((p.M + TH * TW - 1) / (TH * TW)), (unsigned)(p.Cout / (16 * NT)));
   else if (MODE == MODE_Q8) grid = dim3((unsigned)((p.B + 3) / 4), (unsigned)(p.Cout / (16 * NT)));
   else grid = dim3((unsigned)(p.B * p.tiles_h * p.tiles_w), (unsigned)(p.Cout / (16 * NT)));
+  static const DmVariantName vn("conv_mfma<TH=%d,TW=%d,S=%d,NT=%d,MODE=%d>", TH, TW, S, NT, MODE);
+  dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, grid, dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
   return DM_OK;
@@ -549,6 +551,8 @@ int launch_gemm_stream_v(const ConvParams& p, hipStream_t st) {
   // Workgroups are dealt to the 8 XCDs round-robin by linear id (x + y * gx): with gx a multiple of 8 the gy
   // workgroups that stream the same X rows sit on one XCD and share them through its L2.
   if (gy > 1 && gx > 8) gx &= ~7;
+  static const DmVariantName vn("gemm_stream<MT=%d,NT=%d,NKS=%d,WIDE=%d>", MT, NT, NKS, (int)WIDE);
+  dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), LDS, st, p, ntiles);
   DM_LAUNCH_CHECK();
   return DM_OK;

@@ -349,6 +349,8 @@ int launch_wgrad(const WgradParams& p, const Plan& pl, hipStream_t st) {
       return DM_ERR_LAUNCH;
     attr_set = true;
   }
+  static const DmVariantName vn("wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>", TH, TW, S, MODE, TAPS);
+  dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, dim3(pl.nsplit, pl.ncot, pl.ncit), dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
   return DM_OK;

@@ -64,6 +64,23 @@ def normalize_lut() -> torch.Tensor:
     return normalize_uint8(torch.arange(256, dtype=torch.int32).to(torch.uint8))
 
 
+def _rank_shard(order: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Rank ``rank``'s stride of one epoch order.  Every rank must run the SAME number of batches (a rank with one
+    batch more would wait for ever in its gradient all-reduce), so the order is first padded to a multiple of
+    ``world`` by wrapping around to its beginning -- torch's DistributedSampler convention; with world == 1 nothing
+    is added."""
+    n = order.numel()
+    pad = (-n) % world
+    if pad:
+        order = torch.cat([order, order[:pad]])
+    return order[rank::world]
+
+
+def _n_batches(n: int, world: int, batch_size: int, drop_last: bool) -> int:
+    n_local = (n + world - 1) // world          # identical on every rank (see _rank_shard)
+    return n_local // batch_size if drop_last else (n_local + batch_size - 1) // batch_size
+
+
 class STL10Loader:
     """Iterable of ``(x [B,3,96,96] fp32 in [-1,1], labels [B] int64)`` device batches with ``len()``, the interface
     ``main_stl10.train`` expects from ``train_loader``.  The split lives on ``device`` as uint8."""
@@ -83,16 +100,12 @@ class STL10Loader:
         self.rank, self.world = int(rank), int(world_size)  # data-parallel: every rank takes its stride of the epoch order
         self.n = images.shape[0]
 
-    def _n_local(self) -> int:
-        return (self.n - self.rank + self.world - 1) // self.world
-
     def __len__(self) -> int:
-        n = self._n_local()
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return _n_batches(self.n, self.world, self.batch_size, self.drop_last)
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         order = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
-        order = order[self.rank::self.world].to(self.images.device)
+        order = _rank_shard(order, self.rank, self.world).to(self.images.device)
         for i in range(len(self)):
             idx = order[i * self.batch_size:(i + 1) * self.batch_size]
             u8 = self.images.index_select(0, idx)
@@ -123,15 +136,14 @@ class LatentLoader:
         self.n = self.latents.shape[0]
 
     def __len__(self) -> int:
-        n = (self.n - self.rank + self.world - 1) // self.world
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return _n_batches(self.n, self.world, self.batch_size, self.drop_last)
 
     def __getitem__(self, idx: int):
         return self.latents[idx] * self.scaling_factor, self.labels[idx]
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         order = torch.randperm(self.n, generator=self.gen) if self.shuffle else torch.arange(self.n)
-        order = order[self.rank::self.world].to(self.latents.device)
+        order = _rank_shard(order, self.rank, self.world).to(self.latents.device)
         for i in range(len(self)):
             idx = order[i * self.batch_size:(i + 1) * self.batch_size]
             yield self.latents.index_select(0, idx) * self.scaling_factor, self.labels.index_select(0, idx)

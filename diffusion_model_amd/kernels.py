@@ -57,16 +57,32 @@ def _f32(t: Optional[torch.Tensor], what: str):
     return t
 
 
+def last_variant() -> str:
+    """Name of the kernel instantiation the last conv3x3 / gemm / wgrad / attention call of this thread launched
+    (dm_last_variant, include/dm_hip.h): the parity tests assert the size-dependent dispatch through it."""
+    return (_lib.lib().dm_last_variant() or b"").decode()
+
+
 # --------------------------------------------------------------------------- workspace
 _WS = {}
+_WS_RETIRED = []   # outgrown side-stream buffers, kept alive until join_side() (see workspace())
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """A per-(device, stream) scratch buffer that only ever grows (stable under graph replay once warm).
-    Kernels on different streams must not share scratch: the weight-gradient side stream gets its own."""
+    Kernels on different streams must not share scratch: the weight-gradient side stream gets its own.
+
+    A buffer is allocated while torch's CURRENT stream is the main one, so the caching allocator would hand an
+    outgrown block straight back to the next main-stream ``torch.empty``.  For the side stream's buffer that is a
+    race: the split-K weight gradient queued before the growth may still be reading and writing its slabs there.  An
+    outgrown buffer of a forced (side) stream is therefore parked in ``_WS_RETIRED`` and released only by
+    ``join_side``, after the main stream has been ordered behind the side stream."""
+    forced = _FORCED_STREAM[0]
     key = (device.index if isinstance(device, torch.device) else torch.device(device).index, _stream())
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
+        if cur is not None and forced is not None:
+            _WS_RETIRED.append(cur)
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = cur
     return cur
@@ -241,6 +257,24 @@ def join_side(device=None) -> None:
     if key in _SIDE_DIRTY:
         torch.cuda.current_stream(key).wait_stream(_SIDE[key][0])
         _SIDE_DIRTY.discard(key)
+    if _WS_RETIRED and not _SIDE_DIRTY:
+        _WS_RETIRED.clear()   # every stream that could still touch them is ordered before the current one now
+
+
+def call_on_side(device, fn) -> None:
+    """Run ``fn()`` with the weight-gradient side stream as torch's CURRENT stream, ordered after everything enqueued
+    so far on the current stream and on the side stream.  The data-parallel bucket hook issues its asynchronous
+    all-reduce this way: RCCL's internal stream then waits for the side stream (whose fork point covers the main
+    stream's work up to here), so the collective sees the finished gradients of the stage while the MAIN stream is
+    never made to drain the weight-gradient queue (one event per stage instead of a join per bucket)."""
+    dev = torch.device(device)
+    flush_side()
+    side, ev = _side_stream(dev)
+    ev.record()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        fn()
+    _SIDE_DIRTY.add(dev.index or 0)
 
 
 # --------------------------------------------------------------------------- norm

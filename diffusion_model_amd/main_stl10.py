@@ -64,24 +64,39 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
           total_epochs: int = TOTAL_EPOCHS_NEW, start_epoch: int = START_EPOCH, checkpoint_dir: str = ".",
           checkpoint_every: int = 5, on_epoch_end: Optional[Callable] = None, check_finite: bool = True,
           distributed: Optional[bool] = None, log: Callable = print, monitor_dir: Optional[str] = None,
-          monitor_every: int = 1):
+          monitor_every: int = 1, seed: Optional[int] = None):
     """Reference main_stl10.py:352-545.  Returns ``(model, ema, trainer)``.  ``monitor_dir``: when given, the
     reference's end-of-epoch images (:521-524: reconstruction sweep, denoising collage, fixed-seed class grid) are
-    written under it every ``monitor_every`` epochs from the EMA weights, each as one batched sampling job."""
+    written under it every ``monitor_every`` epochs from the EMA weights, each as one batched sampling job.
+
+    Data parallel (``distributed``, default: on when a process group is initialised; one process per GPU under
+    torchrun): every rank reads ITS shard of the epoch order (the loaders' ``rank``/``world_size``), continues from
+    rank 0's parameters / EMA / moments (``Trainer.broadcast_state``), draws label drops, timesteps, noise and dropout
+    masks from rank-offset seeds (``seed``, default ``torch.initial_seed()``), skips a non-finite batch on all ranks
+    or on none, and only rank 0 logs, writes checkpoints and monitoring images."""
+    import torch.distributed as dist
+    if distributed is None:
+        distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    if rank != 0:
+        log = lambda *a, **k: None   # noqa: E731  (one voice per job)
     scheduler = DDPM_beta_t_cosine_scheduler(NUM_TIME_STEPS)
     if train_loader is None and config.LDM:
         # reference utils.py:127-132: pre-computed VAE latents (the latent model, utils.py:145-156); no synthetic
         # stand-in here -- without the file there is nothing to train the latent model on
         from .data import LatentLoader
         train_loader = LatentLoader(os.path.join("docs", "data", "imagenet_latents.pt" if config.IMAGE_NET
-                                                 else "stl10_latents.pt"), batch_size=BATCH_SIZE, device=device)
+                                                 else "stl10_latents.pt"), batch_size=BATCH_SIZE, device=device,
+                                   rank=rank, world_size=world)
     if train_loader is None:
         try:  # reference: torchvision STL10(root='stl10_data', split='train'), shuffled, batch_size BATCH_SIZE
             from .data import STL10Loader
-            train_loader = STL10Loader("stl10_data", "train", batch_size=BATCH_SIZE, shuffle=True, device=device)
+            train_loader = STL10Loader("stl10_data", "train", batch_size=BATCH_SIZE, shuffle=True, device=device,
+                                       rank=rank, world_size=world)
         except FileNotFoundError as exc:
             log(f"[warn] {exc}; using SyntheticLoader")
-            train_loader = SyntheticLoader()
+            train_loader = SyntheticLoader(seed=1234 + rank)
     if utils.CONTEXT_TABLE is None and os.path.exists(clip_table_path):
         utils._load_clip_context_table(clip_table_path)
         log(f"[info] Loaded CLIP context table from {clip_table_path} with dim {utils.CONTEXT_TABLE.shape[-1]}")
@@ -104,15 +119,25 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
             log(f"Checkpoint file not found: {checkpoint_path}")
 
     n_batches = len(train_loader)
+    if distributed and world > 1:   # a custom train_loader may be ragged across ranks: every rank runs the common prefix
+        nb = torch.tensor([n_batches], device=device)
+        dist.all_reduce(nb, op=dist.ReduceOp.MIN)
+        n_batches = int(nb.item())
     accum = max(1, VIRTUAL_BATCH_SIZE_MULTIPLIER)
     total_steps_new = total_epochs * n_batches                      # main_stl10.py:402 (counts batches)
     steps_so_far = start_epoch * ((n_batches + accum - 1) // accum)  # main_stl10.py:441-446
-    if distributed is None:
-        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     trainer = Trainer(model, scheduler, lr=LR, weight_decay=config.WEIGHT_DECAY, betas=config.BETAS,
                       clip=config.GRAD_CLIP, ema_decay=EMA_DECAY, accum=accum, total_steps=total_steps_new,
                       start_step=steps_so_far, ema=ema, distributed=distributed)
     table = utils.CONTEXT_TABLE.to(device) if utils.CONTEXT_TABLE is not None else None
+    # per-batch randomness (label drop, t, noise): the process-global generators, as in the reference -- unless the job is
+    # data parallel or a seed is given: every process starts from the same default seed, so ranks would draw the SAME
+    # timesteps and noise; they get generators seeded (seed, rank) instead
+    g_cpu = g_dev = None
+    if distributed or seed is not None:
+        base = (torch.initial_seed() if seed is None else int(seed)) + 7919 * rank
+        g_cpu = torch.Generator().manual_seed(base)
+        g_dev = torch.Generator(device=device).manual_seed(base + 1)
 
     for epoch in range(start_epoch, total_epochs):
         low_t = config.USING_LOW_T_REWARDING and epoch >= config.LOW_T_REWARDING_WARMUP_EPOCHS
@@ -120,30 +145,37 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
         sum_loss = torch.zeros(1, device=device)
         model.train()
         for i, (x, labels) in enumerate(train_loader):
+            if i >= n_batches:
+                break
             x = x.to(device, non_blocking=True).float()
             labels = labels.to(device)
-            drop_mask = torch.rand(labels.shape[0], device=device) < CFG_P_UNCOND   # main_stl10.py:455-457
+            drop_mask = torch.rand(labels.shape[0], device=device, generator=g_dev) < CFG_P_UNCOND   # main_stl10.py:455-457
             labels_dropped = labels.clone()
             labels_dropped[drop_mask] = UNCOND_ID
-            t = torch.randint(0, NUM_TIME_STEPS, (x.shape[0],)).to(device)         # drawn on the host, as :458
-            e = torch.randn_like(x)
+            t = torch.randint(0, NUM_TIME_STEPS, (x.shape[0],), generator=g_cpu).to(device)  # drawn on the host, as :458
+            e = torch.randn(x.shape, device=device, dtype=x.dtype, generator=g_dev)
             context = table[labels_dropped.long()] if table is not None else None
             do_step = ((i + 1) % accum == 0) or (i + 1 == n_batches)                # main_stl10.py:506
             loss = trainer.micro_step(x, context, t, e, step_now=do_step, check_finite=check_finite)
-            sum_loss += loss.detach().reshape(-1)[:1]
+            if not trainer.last_skipped:   # reference :484-486 `continue`s before `sum_loss += loss.item()` (:504)
+                sum_loss += loss.detach().reshape(-1)[:1]
         log(f"Epoch {epoch + 1} | Loss {float(sum_loss.item()) / max(1, n_batches):.5f}")
         if monitor_dir is not None and (epoch + 1) % max(1, monitor_every) == 0 and utils.CONTEXT_TABLE is not None:
             from . import visualization as V
-            V.reconstruct_sweep(ema.module, scheduler, train_loader, epoch + 1, device, NUM_TIME_STEPS, SAMPLING_ETA,
-                                None, monitor_dir, t_list=[700, 500, 300, 200], guidance_scale=CFG_SCALE)
-            V.generate_denoise_collage(ema.module, scheduler, epoch + 1, 1, [499, 400, 300, 200, 100, 50, 15, 0], device,
-                                       NUM_TIME_STEPS, SAMPLING_ETA, None, monitor_dir, guidance_scale=CFG_SCALE)
+            if rank == 0:   # single-rank jobs: the other ranks would write the same files
+                V.reconstruct_sweep(ema.module, scheduler, train_loader, epoch + 1, device, NUM_TIME_STEPS, SAMPLING_ETA,
+                                    None, monitor_dir, t_list=[700, 500, 300, 200], guidance_scale=CFG_SCALE)
+                V.generate_denoise_collage(ema.module, scheduler, epoch + 1, 1, [499, 400, 300, 200, 100, 50, 15, 0],
+                                           device, NUM_TIME_STEPS, SAMPLING_ETA, None, monitor_dir,
+                                           guidance_scale=CFG_SCALE)
+            # the class grid is batch-sharded over the ranks (one gather at the end): every rank takes part
             grid = generate_fixed_seed_class_grid(ema.module, scheduler, num_time_steps=NUM_TIME_STEPS)
-            V.save_image_strip([g for g in grid], [V.STL10_CLASS_NAMES[i] for i in range(grid.shape[0])],
-                               os.path.join(monitor_dir, f"epoch_{epoch + 1}", f"epoch_{epoch + 1}_fixed_seed_grid.png"))
+            if rank == 0:
+                V.save_image_strip([g for g in grid], [V.STL10_CLASS_NAMES[i] for i in range(grid.shape[0])],
+                                   os.path.join(monitor_dir, f"epoch_{epoch + 1}", f"epoch_{epoch + 1}_fixed_seed_grid.png"))
         if on_epoch_end is not None:
             on_epoch_end(epoch + 1, model, ema, scheduler)
-        if checkpoint_every and (epoch + 1) % checkpoint_every == 0:
+        if checkpoint_every and (epoch + 1) % checkpoint_every == 0 and rank == 0:   # replicas are identical: one writer
             torch.save(_checkpoint_dict(model, trainer, ema),
                        os.path.join(checkpoint_dir, f"stl10_checkpoint_epoch_{epoch + 1}.pt"))
     return model, ema, trainer

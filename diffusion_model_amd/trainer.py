@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
-from .unet import Grads, invalidate_packed_weights, repack_all
+from .unet import Grads, invalidate_packed_weights, repack_all, reseed_dropout
 
 
 def lr_lambda(step: int, total_steps: int) -> float:
@@ -142,12 +142,33 @@ class Trainer:
         self.sched_step = start_step
         self.micro = 0
         self.defer_optimizer = False   # tests: inspect the accumulated gradient before stepping
-        self.world = 1
+        self.world, self.rank = 1, 0
         self.buckets = None
+        self.pg = process_group
+        self.last_skipped = False  # micro_step(check_finite=True) found a non-finite loss and skipped the batch
         if distributed:
+            import torch.distributed as dist
             self.buckets = GradBuckets(self.fp, unet_stage_names(model), process_group)
             self.world = self.buckets.world
+            self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+            self.broadcast_state()
+        # dropout masks: a function of (process seed, rank, optimizer step) -- ranks differ, a resumed run does not
+        # replay step 0's masks (unet.DropoutSeeds)
+        reseed_dropout(None, self.rank, start_step)
         model._bwd_hook = None
+
+    def broadcast_state(self, src: int = 0) -> None:
+        """Data parallel: every rank continues from rank ``src``'s parameters, EMA copy and Adam moments (one
+        broadcast per flat buffer).  Replicas built from process-local RNG state, or of which only one loaded a
+        checkpoint, are made identical here; afterwards they stay identical because every rank applies the same
+        all-reduced gradient."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        for buf in (self.fp.flat, self.ema_flat, self.m, self.v):
+            if buf is not None:
+                dist.broadcast(buf, src=src, group=self.pg)
+        invalidate_packed_weights()
 
     # ------------------------------------------------------------------ one micro-batch
     def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, *,
@@ -175,8 +196,18 @@ class Trainer:
                 self._wtab, self._wtab_key = torch.exp(-self.low_t_weight * steps.float()) / (B * chw), key
             w = self._wtab[t]
         loss, dout = K.mse_loss_fwd_bwd(y, tgt, w.contiguous(), grad_scale=1.0 / self.accum)
-        if check_finite and not bool(torch.isfinite(loss).all().item()):
-            return loss  # reference: "continue" -- no backward, no accumulation-counter change
+        self.last_skipped = False
+        if check_finite:
+            ok = torch.isfinite(loss).all()
+            if self.buckets is not None and self.world > 1:
+                # data parallel: skip on ALL ranks or on none -- a rank that returned alone would never launch its
+                # bucket all-reduces or the optimizer step, and the others would wait for it forever
+                flag = ok.to(torch.int32)
+                self.buckets.dist.all_reduce(flag, op=self.buckets.dist.ReduceOp.MIN, group=self.pg)
+                ok = flag
+            if not bool(ok.item()):
+                self.last_skipped = True
+                return loss  # reference: "continue" -- no backward, no accumulation-counter change
         if self.buckets is not None and last:
             self.model._bwd_hook = self.buckets.launch
         self.model._bwd(dout, saved, self.grads, join=last)

@@ -12,7 +12,6 @@ reference's initial weights bit-for-bit; their ``forward`` is never called.
 """
 from __future__ import annotations
 
-import itertools
 import math
 import os
 from typing import Dict, List, Optional
@@ -26,7 +25,40 @@ BF16 = torch.bfloat16
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 _EPOCH = [0]
-_SEED = itertools.count(0x5EED)
+
+
+class DropoutSeeds:
+    """Iterator of dropout seeds (one per dropout site and forward).  The sequence is a pure function of ``base``:
+    ``reseed`` derives the base from the process seed, the data-parallel rank and the optimizer step, so ranks draw
+    different masks, a resumed run does not replay the masks of step 0, and ``torch.manual_seed`` controls it.  Tests
+    pin a sequence by assigning ``unet._SEED = itertools.count(k)`` (any iterator of ints works)."""
+
+    def __init__(self, base: int = 0x5EED):
+        self.base, self.n = int(base), 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> int:
+        self.n += 1
+        return (self.base + self.n * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+
+    def reseed(self, seed: int, rank: int = 0, step: int = 0) -> None:
+        x = (int(seed) * 0xBF58476D1CE4E5B9 + (int(rank) + 1) * 0x94D049BB133111EB + int(step) * 0xD6E8FEB86659FD93)
+        x &= 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        self.base, self.n = x & 0x7FFFFFFFFFFFFFFF, 0
+
+
+_SEED = DropoutSeeds()
+
+
+def reseed_dropout(seed: Optional[int] = None, rank: int = 0, step: int = 0) -> None:
+    """(Re)start the dropout seed sequence from (seed or torch.initial_seed(), rank, step)."""
+    global _SEED
+    if not isinstance(_SEED, DropoutSeeds):
+        _SEED = DropoutSeeds()
+    _SEED.reseed(torch.initial_seed() if seed is None else seed, rank, step)
 
 
 def invalidate_packed_weights() -> None:
@@ -681,10 +713,12 @@ class UNET(HipModule):
         d_cat = K.conv3x3(d_a1, PW.of(self.late_conv1).bwd, Cc)
         user_hook = self.__dict__.get("_bwd_hook")
 
-        def hook(stage):  # gradients of a finished stage are about to be consumed: join the wgrad stream
+        def hook(stage):
+            # gradients of a finished stage are about to be consumed by the caller's hook (the data-parallel bucket
+            # all-reduce): it is issued from the weight-gradient stream, behind the stage's weight gradients and the
+            # main stream's work so far -- the main stream itself does not wait (kernels.call_on_side)
             if user_hook is not None:
-                K.join_side(da_dev)
-                user_hook(stage)
+                K.call_on_side(da_dev, lambda: user_hook(stage))
 
         da_dev = dout.device
         hook("head")

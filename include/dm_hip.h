@@ -36,6 +36,13 @@ const char* dm_target_arch(void);
 /* Text of the HIP error behind the calling thread's last DM_ERR_LAUNCH ("" if none). */
 const char* dm_last_hip_error(void);
 void dm_note_hip_error(int code);
+/* Name of the kernel instantiation the calling thread's last dm_conv3x3 / dm_gemm / dm_wgrad / dm_attn_* call
+ * launched, e.g. "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=2>" (NT = 16-cout tiles per workgroup; MODE 0 s1, 1 s2,
+ * 2 nearest-x2, 3 zero-insert, 4 implicit-GEMM 1x1, 5 four 8x8 images per tile), "gemm_stream<MT=2,...>",
+ * "wgrad<...>".  The dispatch is size-dependent (unet.py:74-75,225-229,234,317-320 all map onto one entry point),
+ * so parity tests assert through this hook that they verified the instantiation the B=64 training step runs.
+ * Test/diagnostic hook: no reference counterpart. */
+const char* dm_last_variant(void);
 
 /* ------------------------------------------------------------------ weights */
 /* Bytes of the packed bf16 shadow of an [N][K][taps] weight (N padded to 16, K to 64). */

@@ -67,9 +67,21 @@ def test_loader_epochs_shuffle_and_rank_shards(tmp_path):
     a = STL10Loader(str(tmp_path), "train", batch_size=64, shuffle=True, seed=9, rank=0, world_size=2)
     b = STL10Loader(str(tmp_path), "train", batch_size=64, shuffle=True, seed=9, rank=1, world_size=2)
     xa, _ = next(iter(a)); xb, _ = next(iter(b))
-    assert xa.shape[0] + xb.shape[0] == 37
+    # 37 images over 2 ranks: every rank runs the same number of samples/batches (19; a rank with one batch more would
+    # hang in its all-reduce), so the epoch order is padded by wrapping around -- exactly one image is seen twice
+    assert xa.shape[0] == xb.shape[0] == 19 and len(a) == len(b) == 1
     got = [index[key(r)] for r in torch.cat([xa, xb])]
-    assert sorted(got) == list(range(37))
+    assert sorted(set(got)) == list(range(37)) and len(got) == 38
+    ga, gb = [index[key(r)] for r in xa], [index[key(r)] for r in xb]
+    assert len(set(ga)) == 19 and len(set(gb)) == 19 and len(set(ga) & set(gb)) == 1
+    # an evenly divisible split is a partition without overlap
+    write_split(tmp_path / "even", 40, seed=4)
+    la = [STL10Loader(str(tmp_path / "even"), "train", batch_size=4, shuffle=True, seed=2, rank=r, world_size=4) for r in range(4)]
+    assert len({len(l) for l in la}) == 1 and len(la[0]) == 3
+    ref_e = normalize_uint8(torch.from_numpy(read_stl10_binary(str(tmp_path / "even"), "train")[0]))
+    index_e = {key(r): i for i, r in enumerate(ref_e)}
+    per_rank = [[index_e[key(xi)] for x, _ in l for xi in x] for l in la]
+    assert sorted(sum(per_rank, [])) == list(range(40))
 
 
 def test_loader_exact_batches_unshuffled(tmp_path):

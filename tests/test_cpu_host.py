@@ -234,3 +234,100 @@ def test_sharded_sampling_gloo_world2():
     assert [r[3] for r in res] == [(0, 3), (3, 5)]
     for rank, same, one_call, _ in res:
         assert same and one_call, f"rank {rank}: gathered batch differs from the single-process result"
+
+
+def _dp_init_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        from diffusion_model_amd import unet as U
+        from diffusion_model_amd.ema import ModelEmaV2
+        from diffusion_model_amd.trainer import Trainer
+        torch.manual_seed(100 + rank)            # process-local RNG: the replicas START different
+        m = U.UNET(Attentions=[False] * 6)
+        with torch.no_grad():
+            m.output_conv.weight.normal_(0, 0.05)
+        before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+        tr = Trainer(m, None, ema=ModelEmaV2(m, 0.995), distributed=True, start_step=3)
+        assert tr.world == world and tr.rank == rank
+        flats = [torch.empty_like(tr.fp.flat) for _ in range(world)]
+        dist.all_gather(flats, tr.fp.flat)
+        emas = [torch.empty_like(tr.ema_flat) for _ in range(world)]
+        dist.all_gather(emas, tr.ema_flat)
+        befores = [torch.empty_like(before) for _ in range(world)]
+        dist.all_gather(befores, before)
+        same = all(torch.equal(f, flats[0]) for f in flats) and all(torch.equal(e, emas[0]) for e in emas)
+        # the module's parameters alias the flat buffer: they carry rank 0's values now, on every rank
+        now = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+        aliased = torch.equal(now, befores[0])
+        ema_follows = torch.equal(torch.cat([p.detach().reshape(-1) for p in tr.ema.module.parameters()]), befores[0])
+        seeds = [None] * world
+        dist.all_gather_object(seeds, [next(U._SEED) for _ in range(4)])
+        q.put((rank, same, aliased and ema_follows, not torch.equal(befores[0], befores[1]), seeds))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_trainer_init_identical_replicas_gloo_world2():
+    """replicas built from different process-local RNG states continue from rank 0's parameters and EMA copy
+    after Trainer init (one broadcast per flat buffer); dropout seed streams differ between the ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_init_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same, aliased, started_different, seeds in res:
+        assert started_different, "the test must start from different replicas"
+        assert same, f"rank {rank}: flat parameter / EMA buffers differ between ranks after Trainer init"
+        assert aliased, f"rank {rank}: module parameters do not carry rank 0's values"
+        assert seeds[0] != seeds[1] and not (set(seeds[0]) & set(seeds[1])), "ranks must draw different dropout seeds"
+
+
+def test_dropout_seed_stream_is_a_function_of_seed_rank_step():
+    from diffusion_model_amd import unet as U
+    a = U.DropoutSeeds(); a.reseed(7, 0, 0)
+    b = U.DropoutSeeds(); b.reseed(7, 0, 0)
+    c = U.DropoutSeeds(); c.reseed(7, 1, 0)
+    d = U.DropoutSeeds(); d.reseed(7, 0, 5)     # resumed at optimizer step 5: not a replay of step 0
+    sa, sb, sc, sd_ = ([next(s) for _ in range(8)] for s in (a, b, c, d))
+    assert sa == sb and len(set(sa)) == 8
+    assert not (set(sa) & set(sc)) and not (set(sa) & set(sd_))
+    assert all(0 <= v < 2 ** 63 for v in sa)
+
+
+def test_bench_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no launcher environment starts N ranks itself (torch.distributed.run on
+    127.0.0.1) before touching a GPU; with a launcher environment whose WORLD_SIZE differs it refuses to run."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.main()
