@@ -37,24 +37,36 @@ def step_coefficients(beta: torch.Tensor, abar: torch.Tensor, t: int, guidance, 
     return coef.contiguous()
 
 
+def _eps_step(z: torch.Tensor, t: int, predicted_noise: torch.Tensor, scheduler, eta: float, final: bool) -> torch.Tensor:
+    """One DDPM / eta step from a GIVEN epsilon on the fused kernel: with the coefficient row
+    {sqrt(1-abar) := 0, sqrt(abar) := 1, guidance := 0} and v_uncond = v_cond = eps, dm_cfg_ddpm_step's
+    ``eps = sig z + sa (v_u + g (v_c - v_u))`` returns the caller's epsilon unchanged, and the rest of the kernel is
+    the reference's mean step, eta noise and (final) clamp -- no second statement of that arithmetic in torch."""
+    from . import kernels as K
+    if not z.is_cuda:
+        raise RuntimeError("diffusion_model_amd samples only on an AMD GPU (HIP kernels); there is no CPU fallback")
+    B = z.shape[0]
+    beta = getattr(scheduler, "beta_cpu", None)
+    abar = getattr(scheduler, "alpha_bar_cpu", None)
+    if beta is None or abar is None:   # a reference-style scheduler object: tables on some device
+        beta, abar = scheduler.beta_t.detach().float().cpu(), scheduler.alpha_t.detach().float().cpu()
+    coef = step_coefficients(beta, abar, t, 0.0, eta, B, final=final)
+    coef[:, 0], coef[:, 1] = 0.0, 1.0
+    zc = z.contiguous().float()
+    eps = predicted_noise.contiguous().float()
+    noise = torch.randn_like(zc) if float(coef[0, 4]) != 0.0 else zc
+    return K.cfg_ddpm_step(zc, eps, eps, noise, coef.to(z.device))
+
+
 def _ddpm_step(z: torch.Tensor, t: int, predicted_noise: torch.Tensor, scheduler, eta: float) -> torch.Tensor:
-    """Reference visualization.py:92-109 (torch statement kept for callers that use the reference's
-    ``predict_eps_fn`` callback contract; the fast path below fuses all of it into one kernel)."""
-    alpha_bar_t = scheduler.alpha_t[t]
-    beta_t = scheduler.beta_t[t]
-    alpha_t = 1.0 - beta_t
-    alpha_bar_prev = scheduler.alpha_t[t - 1] if t > 0 else torch.tensor(1.0, device=z.device)
-    z = (1.0 / torch.sqrt(alpha_t)) * (z - (beta_t / torch.sqrt(1.0 - alpha_bar_t)) * predicted_noise)
-    if t > 1 and eta > 0.0:
-        noise = torch.randn_like(z)
-        posterior_var = beta_t * (1.0 - alpha_bar_prev) / (1.0 - alpha_bar_t)
-        z = z + eta * torch.sqrt(posterior_var) * noise
-    return z
+    """Reference visualization.py:92-109, for callers that use the reference's ``predict_eps_fn`` callback contract."""
+    return _eps_step(z, t, predicted_noise, scheduler, eta, final=False)
 
 
 def run_reverse_process(model, scheduler, z_init, labels, guidance_scale, eta, num_time_steps, predict_eps_fn,
                         capture_timesteps=None):
-    """Reference visualization.py:112-152, same signature and return value."""
+    """Reference visualization.py:112-152, same signature and return value.  The model evaluations are the
+    caller's ``predict_eps_fn`` (callback contract); every step's arithmetic runs on ``dm_cfg_ddpm_step``."""
     with torch.no_grad():
         model.eval()
         capture_timesteps = capture_timesteps or []
@@ -68,10 +80,9 @@ def run_reverse_process(model, scheduler, z_init, labels, guidance_scale, eta, n
                 snapshots[t] = torch.clamp(z, -1, 1)
         t_tensor = torch.tensor([0], device=z.device)
         eps = predict_eps_fn(model, scheduler, z, t_tensor, labels, guidance_scale)
-        alpha_0 = 1.0 - scheduler.beta_t[0]
-        x0 = (1.0 / torch.sqrt(alpha_0)) * (z - (scheduler.beta_t[0] / torch.sqrt(1.0 - scheduler.alpha_t[0])) * eps)
-        snapshots[0] = torch.clamp(x0, -1, 1)
-        return torch.clamp(x0, -1, 1), snapshots
+        x0 = _eps_step(z, 0, eps, scheduler, eta, final=True)   # t = 0: mean step, no noise, clamp (:144-152)
+        snapshots[0] = x0
+        return x0, snapshots
 
 
 class CFGSampler:
