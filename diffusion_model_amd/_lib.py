@@ -86,6 +86,10 @@ _SIGS = {
     "dm_mse_workspace_bytes": (c_long, [c_int]),
     "dm_mse_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_long,
                                     c_void_p, c_long, c_void_p]),
+    "dm_init_device": (c_int, []),
+    "dm_mse_noalloc_max_batch": (c_int, []),
+    "dm_mse_loss_fwd_bwd_noalloc": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_long,
+                                            c_void_p]),
     "dm_cfg_ddpm_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
                                  c_void_p]),
     "dm_cfg_dpmpp2m_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
@@ -124,7 +128,7 @@ def lib():
 
 def check(code: int, what: str) -> None:
     if code != 0:
-        detail = "bad argument" if code == -1 else "unknown"
+        detail = {-1: "bad argument", -3: "size beyond the entry point's fixed maximum"}.get(code, "unknown")
         if code == -2:
             detail = "launch error: " + (lib().dm_last_hip_error() or b"?").decode()
         raise DmError(f"{what} failed with code {code} ({detail})")

@@ -10,6 +10,8 @@
 //   clip_grad_norm_/AdamW/EMA .. main_stl10.py:508-510 (torch + timm semantics)
 #include "dm_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int EW_BLOCK = 256;
@@ -451,6 +453,56 @@ extern "C" int dm_mse_loss_fwd_bwd(const float* out, const float* v, const float
   DM_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, B * 32,
                      loss);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// ---------------------------------------------------------------- allocation-free variant of dm_mse_loss_fwd_bwd
+// For callers that cannot allocate (HIP graph capture, tight serving / monitoring loops): the per-(sample, block)
+// partial sums live in a file-scope device array instead of a caller-provided workspace.  `scratch` below is a HOST-side
+// stand-in for the symbol: only the address hipGetSymbolAddress returns (per device: every GPU holds its own copy) is
+// ever passed to a kernel.
+constexpr int DM_MSE_NOALLOC_MAX_B = 4096;                      // 4096 samples x 32 block partials x 4 B = 512 KiB per GPU
+static __device__ __align__(256) float scratch[DM_MSE_NOALLOC_MAX_B * 32];
+constexpr int DM_MAX_DEVICES = 64;
+static float* g_scratch_ptr[DM_MAX_DEVICES];                    // device address of `scratch`, per device ordinal
+static std::mutex g_scratch_mu;
+
+// Resolve the scratch array's address on the CURRENT device (once per device).  Returns NULL on failure.
+static float* scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DM_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      dm_note_hip_error((int)e);
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = (float*)ptr;
+  }
+  return g_scratch_ptr[dev];
+}
+
+extern "C" int dm_init_device(void) {
+  (void)hipGetLastError();
+  return scratch_for_current_device() ? DM_OK : DM_ERR_LAUNCH;
+}
+
+extern "C" int dm_mse_noalloc_max_batch(void) { return DM_MSE_NOALLOC_MAX_B; }
+
+extern "C" int dm_mse_loss_fwd_bwd_noalloc(const float* out, const float* v, const float* w, float grad_scale,
+                                           float* dout, float* loss, int B, long chw, dm_stream_t stream) {
+  DM_REQUIRE(out && v && w && loss && B > 0 && chw > 0 && chw % 4 == 0);
+  if (B > DM_MSE_NOALLOC_MAX_B) return DM_ERR_TOO_LARGE;  // the static scratch holds 32 partials for 4096 samples
+  float* ws = scratch_for_current_device();
+  if (!ws) return DM_ERR_LAUNCH;
+  // every partial the second kernel reads is written by the first one in this call (B * 32 of them), so nothing of
+  // the previous call's contents has to be cleared; calls that overlap on one GPU (two streams) race on the array.
+  hipLaunchKernelGGL(mse_kernel, dim3(32, B), dim3(256), 0, (hipStream_t)stream, out, v, w, grad_scale, dout, ws, chw);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, B * 32, loss);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -487,6 +487,17 @@ def mse_loss_fwd_bwd(out, v, w, grad_scale=1.0, want_grad=True):
     return loss, dout
 
 
+def mse_loss_fwd_bwd_noalloc(out, v, w, loss, dout=None, grad_scale=1.0):
+    """dm_mse_loss_fwd_bwd_noalloc (include/dm_hip.h): the caller brings every buffer (``loss`` [1] fp32, optional
+    ``dout``); the library's static device scratch holds the partial sums.  Nothing is allocated here."""
+    B = out.shape[0]
+    chw = out.numel() // B
+    check(_lib.lib().dm_mse_loss_fwd_bwd_noalloc(_p(_f32(out, "out")), _p(_f32(v, "v")), _p(_f32(w, "w")),
+                                                 float(grad_scale), _p(dout), _p(_f32(loss, "loss")), B, chw,
+                                                 _stream()), "dm_mse_loss_fwd_bwd_noalloc")
+    return loss, dout
+
+
 def cfg_ddpm_step(z, v_u, v_c, noise, coef, out=None):
     B = z.shape[0]
     chw = z.numel() // B

@@ -29,6 +29,7 @@ typedef void* dm_stream_t;
 #define DM_OK 0
 #define DM_ERR_ARG (-1)
 #define DM_ERR_LAUNCH (-2)
+#define DM_ERR_TOO_LARGE (-3)   /* a size beyond an entry point's documented fixed maximum */
 
 /* ABI version / arch string ("gfx950"). */
 int dm_abi_version(void);
@@ -198,6 +199,20 @@ long dm_mse_workspace_bytes(int B);
 /* loss = sum_b w[b] * sum_chw (out-v)^2 ; dout = 2 w[b] grad_scale (out-v)   (main_stl10.py:477-482,502). */
 int dm_mse_loss_fwd_bwd(const float* out, const float* v, const float* w, float grad_scale, float* dout,
                         float* loss, int B, long chw, void* workspace, long ws_bytes, dm_stream_t stream);
+/* Allocation-free variant of dm_mse_loss_fwd_bwd.  NO counterpart in the reference: it exists for callers that
+ * cannot allocate device memory or bring a workspace -- code under HIP graph capture, tight serving / monitoring
+ * loops, harnesses that forbid hipMalloc.  Same kernels and results as dm_mse_loss_fwd_bwd; the per-(sample, block)
+ * partial sums live in a static device array of the library (512 KiB, held on every GPU the library runs on until
+ * the process ends) instead of a caller workspace.  Calls no hipMalloc / hipFree / allocating routine.
+ *   - B <= dm_mse_noalloc_max_batch() (4096); larger B returns DM_ERR_TOO_LARGE and launches nothing.
+ *   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.
+ *   - dm_init_device() resolves the array's address for the CURRENT device (hipGetSymbolAddress, once per device);
+ *     the entry point does the same on its first call on a device -- call dm_init_device() up front when the first
+ *     call would otherwise fall inside a stream capture. */
+int dm_init_device(void);
+int dm_mse_noalloc_max_batch(void);
+int dm_mse_loss_fwd_bwd_noalloc(const float* out, const float* v, const float* w, float grad_scale, float* dout,
+                                float* loss, int B, long chw, dm_stream_t stream);
 /* One fused sampler step: CFG combine on v, v->eps, DDPM mean step, eta-scaled noise, optional
  * clamp.  coef[b][8] = {sqrt(1-abar_t), sqrt(abar_t), 1/sqrt(alpha_t), beta_t/sqrt(1-abar_t),
  * eta*sqrt(posterior_var) (0 = no noise), guidance scale, clamp flag, unused}.
