@@ -128,75 +128,106 @@ def latent_leg(a, dev, table, sched):
     return out
 
 
-def time_dominant_kernel(B, dev, reps=20):
-    """Live HIP-event timing of the dominant MFMA kernel: nearest-x2 + conv3x3 at the L4.upsample.conv shape
-    (2.72 of the 18.08 forward GFLOP per image), on the stream it is launched on.  Returns (avg_seconds, flops_per_launch)."""
+def time_conv_kernel(B, dev, H=48, cin=128, cout=128, mode=2, reps=20):
+    """Live HIP-event timing of one conv launch shape, back to back on the stream it is launched on.  Default: the
+    dominant MFMA kernel, nearest-x2 + conv3x3 at the L4.upsample.conv shape (2.72 of the 18.08 forward GFLOP per
+    image).  Returns (avg_seconds, flops_per_launch, kernel variant name)."""
     from diffusion_model_amd import kernels as K
-    shapes = [(48, 128, 128)]  # (input H=W, Cin, Cout): L4.upsample.conv, the largest single conv of the step
-    tot, flops = 0.0, 0.0
-    for H, cin, cout in shapes:
-        x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
-        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
-        wp = K.pack_weight(w)
-        bias = torch.zeros(cout, device=dev)
-        y = torch.empty(B, 2 * H, 2 * H, cout, dtype=torch.bfloat16, device=dev)
-        for _ in range(3):
-            K.conv3x3(x, wp, cout, bias=bias, mode=2, out=y)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(reps):
-            K.conv3x3(x, wp, cout, bias=bias, mode=2, out=y)
-        e.record()
-        e.synchronize()
-        tot += s.elapsed_time(e) * 1e-3 / reps
-        flops += 2.0 * B * (2 * H) * (2 * H) * cout * cin * 9
-    return tot / len(shapes), flops / len(shapes)
+    x = torch.randn(B, H, H, cin, device=dev).to(torch.bfloat16)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
+    wp = K.pack_weight(w)
+    bias = torch.zeros(cout, device=dev)
+    Ho = H // 2 if mode == 1 else (2 * H if mode in (2, 3) else H)
+    y = torch.empty(B, Ho, Ho, cout, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        K.conv3x3(x, wp, cout, bias=bias, mode=mode, out=y)
+    variant = K.last_variant()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        K.conv3x3(x, wp, cout, bias=bias, mode=mode, out=y)
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps, 2.0 * B * Ho * Ho * cout * cin * 9, variant
 
 
 def cpu_baseline():
-    """The oracle (CPU fp32 restatement of the reference) timed on this box's host cores: config C1
-    (B=8, 96x96, CLIP context, v-loss with low-t weighting, clip 1.0, AdamW), dropout 0, 1 warm-up +
-    3 timed optimizer steps (about 10-20 s of CPU work).  A reported baseline, not a target."""
+    """The oracle (CPU fp32 restatement of the reference, oracle/) timed on this box's host cores, SURVEY.md 8(d):
+    config C1 = B=8, 96x96, CLIP context, v-loss with low-t weighting, clip 1.0, AdamW, same synthetic recipe --
+    (a) dropout 0.1, the configuration the reference ships (main_stl10.py:370) and the headline uses: 1 warm-up + 2
+        timed optimizer steps (the attention-probability dropout makes torch materialise the [8,8,2304,2304] matrix:
+        seconds per step);
+    (b) dropout 0.0 ("parity mode"): 2 warm-up + 5 timed steps;
+    (c) a 20-step slice of the B=1 CFG sampler (2 forwards per step, main_stl10.py:125-129), extrapolated to 500.
+    About 20-30 s of CPU work in all.  A reported baseline, not a target."""
     from oracle import diffusion_ref as dref
     from oracle import unet_ref as oref
     import numpy as np
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    spec = oref.UNetSpec(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0)
-    g = torch.Generator().manual_seed(0)
-    sd = {k: v.requires_grad_() for k, v in oref.seeded_fill(oref.param_shapes(spec), 0, 1.0).items()}
-    names = list(sd)
-    m = {k: torch.zeros_like(v) for k, v in sd.items()}
-    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
-    tab = np.load(os.path.join(ROOT, "diffusion_model_amd", "artifacts", "clip", "clip_text_emb_stl10_vitb32.npz"),
-                  allow_pickle=False)["embeddings_norm"].astype(np.float32)
+    tab = torch.from_numpy(np.load(os.path.join(ROOT, "diffusion_model_amd", "artifacts", "clip",
+                                                "clip_text_emb_stl10_vitb32.npz"),
+                                   allow_pickle=False)["embeddings_norm"].astype(np.float32))
     beta, alpha, abar = dref.cosine_schedule(500)
     B = 8
 
-    def step(i):
-        x = torch.clamp(torch.randn(B, 3, 96, 96, generator=g) * 0.5, -1, 1)
-        t = torch.randint(0, 500, (B,), generator=g)
-        e = torch.randn(B, 3, 96, 96, generator=g)
-        ctx = torch.from_numpy(tab)[torch.randint(0, 11, (B,), generator=g)]
-        xt, v = dref.q_sample_v_target(x, e, abar[t])
-        out = oref.unet_forward(sd, spec, xt, t, ctx)
-        loss = dref.v_loss(out, v, t, 0.01)
-        grads = list(torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True))
-        grads = [gg if gg is not None else torch.zeros_like(sd[k]) for gg, k in zip(grads, names)]
-        dref.clip_grad_norm(grads, 1.0)
-        with torch.no_grad():
-            for k, gg in zip(names, grads):
-                dref.adamw_step(sd[k], gg, m[k], vv[k], i + 1, 5e-5)
+    def train_leg(dropout, warm, n):
+        spec = oref.UNetSpec(input_channels=3, output_channels=3, context_dim=512, dropout_prob=dropout)
+        g = torch.Generator().manual_seed(0)
+        torch.manual_seed(0)   # F.dropout draws from the global generator
+        sd = {k: v.requires_grad_() for k, v in oref.seeded_fill(oref.param_shapes(spec), 0, 1.0).items()}
+        names = list(sd)
+        m = {k: torch.zeros_like(v) for k, v in sd.items()}
+        vv = {k: torch.zeros_like(v) for k, v in sd.items()}
 
-    step(0)
-    t0 = time.perf_counter()
-    n = 3
-    for i in range(n):
-        step(i + 1)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": B / dt, "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": f"{n} optimizer steps of B={B} 96x96 fp32 (fwd+bwd+clip+AdamW, dropout 0, no accumulation) "
-                      f"after 1 warm-up; torch {torch.__version__} CPU, {threads} threads"}
+        def step(i):
+            x = torch.clamp(torch.randn(B, 3, 96, 96, generator=g) * 0.5, -1, 1)
+            t = torch.randint(0, 500, (B,), generator=g)
+            e = torch.randn(B, 3, 96, 96, generator=g)
+            ctx = tab[torch.randint(0, 11, (B,), generator=g)]
+            xt, v = dref.q_sample_v_target(x, e, abar[t])
+            out = oref.unet_forward(sd, spec, xt, t, ctx, train=dropout > 0)
+            loss = dref.v_loss(out, v, t, 0.01)
+            grads = list(torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True))
+            grads = [gg if gg is not None else torch.zeros_like(sd[k]) for gg, k in zip(grads, names)]
+            dref.clip_grad_norm(grads, 1.0)
+            with torch.no_grad():
+                for k, gg in zip(names, grads):
+                    dref.adamw_step(sd[k], gg, m[k], vv[k], i + 1, 5e-5)
+
+        for i in range(warm):
+            step(i)
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(warm + i)
+        return B / ((time.perf_counter() - t0) / n), sd
+
+    v01, _ = train_leg(0.1, 1, 2)
+    v00, sd = train_leg(0.0, 2, 5)
+    # (c) CFG sampling slice: the reference's own shape -- one image, uncond then cond forward per step
+    spec = oref.UNetSpec(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0)
+    sdd = {k: v.detach() for k, v in sd.items()}
+    z = torch.randn(1, 3, 96, 96, generator=torch.Generator().manual_seed(42))
+    with torch.no_grad():
+        v_fn = lambda zz, tt, cc: oref.unet_forward(sdd, spec, zz, tt, cc)  # noqa: E731
+        dref.reverse_process(v_fn, z, tab[3:4], tab[10:11], 6.0, 1.0, 500, beta, abar, t_stop=498)   # 2 warm-up steps
+        t0 = time.perf_counter()
+        dref.reverse_process(v_fn, z, tab[3:4], tab[10:11], 6.0, 1.0, 500, beta, abar, t_stop=480)   # steps 499..480
+        per_step = (time.perf_counter() - t0) / 20
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": v01, "unit": "img/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+            "sample": f"oracle (fp32 CPU restatement of the reference), B={B} 96x96, fwd+bwd+clip+AdamW, no accumulation, "
+                      f"dropout 0.1 as shipped: 1 warm-up + 2 timed optimizer steps; torch {torch.__version__} CPU, "
+                      f"{threads} threads",
+            "dropout_0": {"value": v00, "unit": "img/s", "sample": "same, dropout 0.0: 2 warm-up + 5 timed steps"},
+            "sampling": {"value": 1.0 / (500 * per_step), "unit": "img/s", "seconds_per_step": per_step,
+                         "sample": "B=1 CFG sampler, 2 forwards per step, 20 timed steps (t = 499..480) extrapolated "
+                                   "to 500 steps"}}
 
 
 def launch_ranks(n: int) -> int:
@@ -421,7 +452,7 @@ def main():
     if world == 1 and not a.no_latent and not a.no_elided:
         out["latent_unet"] = latent_leg(a, dev, table, sched)
     if not a.no_roofline:
-        iso_sec, fl = time_dominant_kernel(a.batch, dev)
+        iso_sec, fl, variant = time_conv_kernel(a.batch, dev)
         sec = iso_sec
         if probe and probe["pairs"]:
             sec = sum(e0.elapsed_time(e1) for e0, e1 in probe["pairs"]) * 1e-3 / len(probe["pairs"])
@@ -433,11 +464,22 @@ def main():
             traffic = json.load(open(pmc))["traffic_bytes"]
         out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": fl / sec / PEAK_BF16, "traffic": traffic,
-                           "kernel": "conv_mfma_kernel<16,16,1,18,160,8,MODE_UP> (nearest-x2 + conv3x3, B=%d)" % a.batch,
+                           "kernel": "%s: nearest-x2 + conv3x3 128->128 48->96 (L4.upsample.conv), B=%d" % (variant, a.batch),
                            "avg_launch_us": sec * 1e6, "flop_per_launch": fl,
                            "launches_timed": len(probe["pairs"]) if probe else 0,
                            "timed_where": "inside the timed training steps (HIP events around each launch)",
                            "isolated_back_to_back_us": iso_sec * 1e6}
+        # the other conv instantiations of the step, back to back after the legs (the 64-cout tile is the top line of
+        # the rocprof table by total time; stride 2 is the slowest per flop)
+        others = []
+        for what, H, cin, cout, mode in (("L1.conv / late_conv2 64->64 @96x96", 96, 64, 64, 0),
+                                         ("late_conv1 128->64 @96x96", 96, 128, 64, 0),
+                                         ("L2.conv2 128->128 @48x48", 48, 128, 128, 0),
+                                         ("L1.downsample stride 2 64->64 96->48", 96, 64, 64, 1)):
+            sec_o, fl_o, var_o = time_conv_kernel(a.batch, dev, H, cin, cout, mode)
+            others.append({"kernel": f"{var_o}: {what}", "avg_launch_us": sec_o * 1e6,
+                           "achieved": fl_o / sec_o / 1e12, "frac": fl_o / sec_o / PEAK_BF16})
+        out["roofline"]["other_conv_kernels_back_to_back"] = others
     if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

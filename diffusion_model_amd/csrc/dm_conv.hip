@@ -23,6 +23,9 @@
 // 160-163,261,320,333-335) and their autograd data-gradients.
 #include "dm_common.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 namespace {
 
 // MODE_Q8: stride-1 conv on 8x8 images, FOUR images per workgroup tile (the latent model's innermost stage): each image
@@ -634,6 +637,23 @@ __global__ void pack_weight_batch_kernel(const dm_pack_desc* __restrict__ d, int
                     (long)(blockIdx.x - e.block_begin) * blockDim.x + threadIdx.x, (long)e.nblocks * blockDim.x);
 }
 
+// Tile choice for the stride-1 family (modes S1 / UP / ZI).  tile: 0 = 16x16, 1 = 8x24, 2 = 8x8; nt: 4 or 8.
+void pick_tile(int B, int Ho, int Wo, int Cin, int Cout, bool pool2, int* tile, int* nt) {
+  auto up = [](int v, int t) { return (v + t - 1) / t; };
+  static const int TH_[3] = {16, 8, 8}, TW_[3] = {16, 24, 8};
+  const bool can128 = (Cout % 128 == 0);
+  // round-1 rule: least padded area (ties to the larger tile); 128 couts when that grid has >= 2 rounds
+  const long a16 = (long)up(Ho, 16) * 16 * up(Wo, 16) * 16, a24 = (long)up(Ho, 8) * 8 * up(Wo, 24) * 24,
+             a8 = (long)up(Ho, 8) * 8 * up(Wo, 8) * 8;
+  int t = 2;
+  if (pool2 || (a16 <= a24 && a16 <= a8)) t = 0;
+  else if (a24 <= a8) t = 1;
+  const long tiles = (long)B * up(Ho, TH_[t]) * up(Wo, TW_[t]);
+  *tile = t;
+  *nt = (can128 && tiles * (Cout / 128) >= 1024) ? 8 : 4;
+  (void)Cin;
+}
+
 }  // namespace
 
 extern "C" long dm_packed_weight_bytes(int N, int K, int taps) {
@@ -689,15 +709,6 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   else if (mode == 2 || mode == 3) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
   else { p.Ho = a->H; p.Wo = a->W; }
   DM_REQUIRE(!p.pool2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
-  bool wide = (a->Cout % 128 == 0);
-#define DM_GO(TH, TW, S, PITCH, STRIDE, MODE)                                          \
-  do {                                                                                 \
-    p.tiles_h = (p.Ho + TH - 1) / TH; p.tiles_w = (p.Wo + TW - 1) / TW;                \
-    /* under two rounds of 128-cout workgroups (512 resident) the 64-cout tile fills the CUs better: measured */ \
-    if ((long)p.B * p.tiles_h * p.tiles_w * (a->Cout / 128) < 1024) wide = false;       \
-    if (wide) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);            \
-    return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
-  } while (0)
   if (mode == 0 && a->H == 8 && a->W == 8 && a->B >= 4 && !p.pool2) {
     // 8x8 images (the latent model's innermost stage: 4096 pixels against K*N up to 9216 x 1024): four images per
     // workgroup; 32-cout workgroups when the 64-cout grid would leave CUs idle
@@ -705,17 +716,42 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
     if ((long)quads * (a->Cout / 64) >= 256) return launch_conv<16, 16, 1, 20, 160, 4, MODE_Q8>(p, st);
     return launch_conv<16, 16, 1, 20, 160, 2, MODE_Q8>(p, st);
   }
+  // ---- tile shape and cout tile.  Candidates: 16x16, 8x24, 8x8 output pixels x {64, 128} couts (stride 2: 8x8
+  // only; pool2 needs whole row pairs per wave: 16x16).  The launch runs in rounds of SLOTS resident workgroups
+  // (2 per CU), so its time is ~ rounds x per-workgroup time, and the per-workgroup time is a fixed part (patch /
+  // weight prologue, epilogue) plus the MFMA work of its pixels x couts (edge tiles compute their padding too).
+  // pick_tile() scores every candidate with that model (constants fitted to tools/convtile.py sweeps); the least
+  // padded area alone (the round-1 rule) left e.g. the 48x48 layers at 2.25 rounds of 16x16 tiles where 8x24 tiles
+  // fill exactly 3 rounds of workgroups three quarters the size.
+  int tile = 2, nt = 4;   // stride 2: 8x8 outputs
+  const bool can128 = (a->Cout % 128 == 0);
+  if (mode == 1) {
+    p.tiles_h = (p.Ho + 7) / 8; p.tiles_w = (p.Wo + 7) / 8;
+    nt = (can128 && (long)p.B * p.tiles_h * p.tiles_w * (a->Cout / 128) >= 1024) ? 8 : 4;
+  } else {
+    pick_tile(p.B, p.Ho, p.Wo, a->Cin, a->Cout, p.pool2 != 0, &tile, &nt);
+  }
+  if (const char* f = getenv("DM_CONV_FORCE")) {   // developer override "tile,nt" (tools/convtile.py); -1 = keep
+    int ft = -1, fn = -1;
+    if (sscanf(f, "%d,%d", &ft, &fn) >= 1) {
+      if (mode != 1 && !p.pool2 && ft >= 0 && ft <= 2) tile = ft;
+      if ((fn == 4 || (fn == 8 && can128))) nt = fn;
+    }
+  }
+  static const int TH_[3] = {16, 8, 8}, TW_[3] = {16, 24, 8};
+  p.tiles_h = (p.Ho + TH_[tile] - 1) / TH_[tile]; p.tiles_w = (p.Wo + TW_[tile] - 1) / TW_[tile];
+#define DM_GO(TH, TW, S, PITCH, STRIDE, MODE)                                          \
+  do {                                                                                 \
+    if (nt == 8) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE>(p, st);         \
+    return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
+  } while (0)
   if (mode == 1) DM_GO(8, 8, 2, 24, 144, MODE_S2);
-  // tile shape = the one that covers the image with the least padded area (edge tiles are masked);
-  // ties go to the larger tile (fewer halo bytes per pixel). pool2 needs whole row pairs per wave: 16x16.
-  auto padded = [&](int th, int tw) { return (long)((p.Ho + th - 1) / th * th) * ((p.Wo + tw - 1) / tw * tw); };
-  const long a16 = padded(16, 16), a24 = padded(8, 24), a8 = padded(8, 8);
-  if (p.pool2 || (a16 <= a24 && a16 <= a8)) {
+  if (tile == 0) {
     if (mode == 0) DM_GO(16, 16, 1, 18, 160, MODE_S1);
     if (mode == 2) DM_GO(16, 16, 1, 18, 160, MODE_UP);
     DM_GO(16, 16, 1, 18, 160, MODE_ZI);
   }
-  if (a24 <= a8) {
+  if (tile == 1) {
     if (mode == 0) DM_GO(8, 24, 1, 32, 160, MODE_S1);
     if (mode == 2) DM_GO(8, 24, 1, 32, 160, MODE_UP);
     DM_GO(8, 24, 1, 32, 160, MODE_ZI);
