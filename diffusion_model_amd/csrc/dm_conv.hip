@@ -638,19 +638,31 @@ __global__ void pack_weight_batch_kernel(const dm_pack_desc* __restrict__ d, int
 }
 
 // Tile choice for the stride-1 family (modes S1 / UP / ZI).  tile: 0 = 16x16, 1 = 8x24, 2 = 8x8; nt: 4 or 8.
+// Rule 1 (round 1): the tile with the least padded area (edge tiles compute their padding), ties to the larger tile
+// (fewer halo bytes per pixel); 128 couts when that grid still has two rounds of the 512 resident workgroups.
+// Rule 2 (tools/convtile.py sweep, B=64, profiles/r02_convtile.txt): when 8x24 tiles cover the image as exactly as
+// 16x16 tiles do and the 16x16 grid is under three rounds, the smaller 8x24 workgroups balance better over the CUs
+// (48x48 outputs: 3.0 rounds of 192-pixel tiles instead of 2.25 of 256-pixel ones) and 128 couts per workgroup pay
+// again: L2.conv2 49.8 -> 46.6 us, L4.conv1 87.0 -> 81.2, zero-insert dgrad of L2.down 49.5 -> 43.9, dgrad of L2.conv1
+// 33.3 -> 29.3.  At 96x96 (4.5+ rounds) 16x16 stays faster (58.6 vs 62.5 us), at 24x24 8x24/64 couts (rule 1).
 void pick_tile(int B, int Ho, int Wo, int Cin, int Cout, bool pool2, int* tile, int* nt) {
   auto up = [](int v, int t) { return (v + t - 1) / t; };
   static const int TH_[3] = {16, 8, 8}, TW_[3] = {16, 24, 8};
   const bool can128 = (Cout % 128 == 0);
-  // round-1 rule: least padded area (ties to the larger tile); 128 couts when that grid has >= 2 rounds
   const long a16 = (long)up(Ho, 16) * 16 * up(Wo, 16) * 16, a24 = (long)up(Ho, 8) * 8 * up(Wo, 24) * 24,
              a8 = (long)up(Ho, 8) * 8 * up(Wo, 8) * 8;
   int t = 2;
   if (pool2 || (a16 <= a24 && a16 <= a8)) t = 0;
   else if (a24 <= a8) t = 1;
-  const long tiles = (long)B * up(Ho, TH_[t]) * up(Wo, TW_[t]);
+  long tiles = (long)B * up(Ho, TH_[t]) * up(Wo, TW_[t]);
+  int n = (can128 && tiles * (Cout / 128) >= 1024) ? 8 : 4;
+  if (t == 0 && !pool2 && a24 == a16 && tiles * (Cout / (16 * n)) < 1536) {
+    t = 1;
+    tiles = (long)B * up(Ho, 8) * up(Wo, 24);
+    n = (can128 && tiles * (Cout / 128) >= 512) ? 8 : 4;
+  }
   *tile = t;
-  *nt = (can128 && tiles * (Cout / 128) >= 1024) ? 8 : 4;
+  *nt = n;
   (void)Cin;
 }
 
@@ -717,12 +729,7 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
     return launch_conv<16, 16, 1, 20, 160, 2, MODE_Q8>(p, st);
   }
   // ---- tile shape and cout tile.  Candidates: 16x16, 8x24, 8x8 output pixels x {64, 128} couts (stride 2: 8x8
-  // only; pool2 needs whole row pairs per wave: 16x16).  The launch runs in rounds of SLOTS resident workgroups
-  // (2 per CU), so its time is ~ rounds x per-workgroup time, and the per-workgroup time is a fixed part (patch /
-  // weight prologue, epilogue) plus the MFMA work of its pixels x couts (edge tiles compute their padding too).
-  // pick_tile() scores every candidate with that model (constants fitted to tools/convtile.py sweeps); the least
-  // padded area alone (the round-1 rule) left e.g. the 48x48 layers at 2.25 rounds of 16x16 tiles where 8x24 tiles
-  // fill exactly 3 rounds of workgroups three quarters the size.
+  // only; pool2 needs whole row pairs per wave: 16x16); pick_tile() holds the rule and the measurements behind it.
   int tile = 2, nt = 4;   // stride 2: 8x8 outputs
   const bool can128 = (a->Cout % 128 == 0);
   if (mode == 1) {

@@ -261,6 +261,49 @@ def join_side(device=None) -> None:
         _WS_RETIRED.clear()   # every stream that could still touch them is ordered before the current one now
 
 
+# A second auxiliary stream for forward work that nothing on the critical path waits for (unet.UnetLayer: with a
+# one-token context the cross-attention output does not depend on its query input, so the self-attention block, the
+# to_q / to_k projections and the log-sum-exp feed nothing the main chain needs before the backward pass).
+_AUX = {}
+_AUX_DIRTY = set()
+
+
+def aux_stream(device):
+    key = torch.device(device).index or 0
+    st = _AUX.get(key)
+    if st is None:
+        st = (torch.cuda.Stream(device=device), torch.cuda.Event())
+        _AUX[key] = st
+    return st
+
+
+class on_aux:
+    """``with on_aux(device):`` -- launches (and torch allocations) inside go to the auxiliary stream, ordered after
+    everything enqueued so far on the current stream.  ``join_aux`` makes the current stream wait for it."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+
+    def __enter__(self):
+        aux, ev = aux_stream(self.dev)
+        ev.record()
+        aux.wait_event(ev)
+        self.ctx = torch.cuda.stream(aux)
+        self.ctx.__enter__()
+        _AUX_DIRTY.add(self.dev.index or 0)
+        return aux
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_aux(device) -> None:
+    key = torch.device(device).index or 0
+    if key in _AUX_DIRTY:
+        torch.cuda.current_stream(key).wait_stream(_AUX[key][0])
+        _AUX_DIRTY.discard(key)
+
+
 def call_on_side(device, fn) -> None:
     """Run ``fn()`` with the weight-gradient side stream as torch's CURRENT stream, ordered after everything enqueued
     so far on the current stream and on the side stream.  The data-parallel bucket hook issues its asynchronous

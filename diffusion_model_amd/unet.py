@@ -345,13 +345,14 @@ class Attention(HipModule):
         self.use_flash_attention = use_flash_attention
         self.C = C
 
-    def _fwd(self, x, res=None, out=None):
+    def _fwd(self, x, res=None, out=None, seed=None):
         B, H, W, C = x.shape
         tok = x.view(B, H * W, C)
         qkv = K.gemm(tok, PW.of(self.linear_qkv).fwd, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         p = self.dropout_prob if self.training else 0.0
-        seed = next(_SEED) if p > 0 else 0
+        if seed is None:
+            seed = next(_SEED) if p > 0 else 0
         o, lse = K.attn_fwd(q, k, v, self.num_heads, drop_p=p, drop_seed=seed)
         y = K.gemm(o, PW.of(self.linear_out).fwd, C, res=None if res is None else res.view(B, H * W, C),
                    out=None if out is None else out.view(B, H * W, C))
@@ -523,6 +524,13 @@ class Downsample(HipModule):
 ELIDE_DEAD_ATTENTION = [os.environ.get("DM_ELIDE_DEAD_ATTENTION", "0") == "1"]
 
 
+# The same data-flow fact used for SCHEDULING instead of elision (on by default; DM_OVERLAP_DEAD_ATTENTION=0 turns it
+# off): everything still runs, but the branch nothing on the critical path waits for -- self-attention, to_q, to_k and
+# the attention call that yields the log-sum-exp -- is enqueued on an auxiliary HIP stream, where its VALU-bound
+# kernels run beside the MFMA-bound convolutions of the main chain.  The main stream joins it at the end of the forward.
+OVERLAP_DEAD_ATTENTION = [os.environ.get("DM_OVERLAP_DEAD_ATTENTION", "1") != "0"]
+
+
 class UnetLayer(HipModule):
     """Reference unet.py:239-285."""
 
@@ -558,6 +566,8 @@ class UnetLayer(HipModule):
             if has_a and self.attention.training and self.attention.dropout_prob > 0:
                 next(_SEED)  # keep the dropout seed sequence of the un-elided network
             xo, s_c = self.cross_attention._fwd(r, ctx, res=r, out=dst, elide=True)
+        elif has_a and has_c and OVERLAP_DEAD_ATTENTION[0] and ctx.shape[1] == 1:
+            xo, s_a, s_c = self._fwd_attn_overlapped(r, ctx, dst)
         elif has_a and has_c:
             xa, s_a = self.attention._fwd(r)
             xo, s_c = self.cross_attention._fwd(xa, ctx, res=r, out=dst)
@@ -576,6 +586,30 @@ class UnetLayer(HipModule):
             return y, xo, (s_res, s_a, s_c, s_u, u)
         y, s_d = self.downsample._fwd(xo)
         return y, xo, (s_res, s_a, s_c, s_d, None)
+
+    def _fwd_attn_overlapped(self, r, ctx, dst):
+        """x = cross_attention(attention(r), ctx) + r for a ONE-token context, scheduled on two streams.  The
+        cross-attention output is to_out(dropout(to_v(ctx))) whatever its query input (softmax over one key), so the
+        main stream computes exactly that and goes on; self-attention, to_q, to_k and the attention call that returns
+        the log-sum-exp run on the auxiliary stream (same kernels, same dropout seeds, same saved tensors as the
+        single-stream order)."""
+        ca, at = self.cross_attention, self.attention
+        B, H, W, C = r.shape
+        N = H * W
+        p_a = at.dropout_prob if at.training else 0.0
+        seed_a = next(_SEED) if p_a > 0 else 0          # the single-stream order draws attention's seed first
+        p_c = ca.dropout_prob if ca.training else 0.0
+        seed_c = next(_SEED) if p_c > 0 else 0
+        vc = K.gemm(ctx, PW.of(ca.to_v).fwd, C)
+        with K.on_aux(r.device):
+            xa, s_a = at._fwd(r, seed=seed_a)
+            tok = xa.view(B, N, C)
+            q = K.gemm(tok, PW.of(ca.to_q).fwd, C)
+            kc = K.gemm(ctx, PW.of(ca.to_k).fwd, C)
+            _, lse = K.attn_fwd(q, kc, vc, ca.num_heads, drop_p=p_c, drop_seed=seed_c)
+        o = K.attn_onekey_fwd(vc, N, ca.num_heads, drop_p=p_c, drop_seed=seed_c)
+        y = K.gemm(o, PW.of(ca.to_out).fwd, C, res=r.view(B, N, C), out=None if dst is None else dst.view(B, N, C))
+        return y.view(B, H, W, C), s_a, (tok, ctx, q, kc, vc, o, lse, p_c, seed_c)
 
     def _bwd(self, dy, d_skip, saved, g: Grads, dts=None, need_dx=True):
         s_res, s_a, s_c, s_ud, u = saved
@@ -689,6 +723,7 @@ class UNET(HipModule):
         K.gemm(a2.view(Bc, Hc * Wc, Cc // 2), PW.of(self.output_conv).fwd, npad, bias=PW.of(self.output_conv).bias_pad(npad),
                act_silu_in=True, out_f32=of.view(Bc, Hc * Wc, npad), n_valid=self.cout_img)
         y = K.nhwc_to_nchw(of, self.cout_img)
+        K.join_aux(dev_)   # the overlapped attention branches (UnetLayer._fwd_attn_overlapped) are part of this forward
         return y, (x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2)
 
     # ------------------------------------------------------------------ hand-scheduled backward

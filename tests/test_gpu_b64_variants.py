@@ -57,11 +57,14 @@ def _conv_ref(x, w, bias, mode):
 # (B, H, Cin, Cout, mode, expected variant) -- H = W = INPUT size.  The layers named are the STL10 UNet's at B=64.
 CONV_FWD = [
     (64, 48, 128, 128, 2, "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=2>"),   # L4.upsample.conv: bench.py's roofline kernel
-    (64, 24, 256, 256, 2, "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=2>"),   # L3.upsample.conv
+    (64, 24, 256, 256, 2, "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=2>"),    # L3.upsample.conv (48x48 out: 8x24 tiles)
     (64, 96, 64, 128, 0, "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=0>"),    # dgrad of late_conv1 (128 <- 64 @ 96x96)
     (64, 96, 64, 64, 0, "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"),     # L1.conv1/conv2, late_conv2: top of the profile
     (64, 96, 128, 64, 0, "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"),    # late_conv1
-    (64, 48, 256, 128, 0, "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"),   # L4.conv1 (576 workgroups: 64-cout tile)
+    (64, 48, 256, 128, 0, "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=0>"),    # L4.conv1 (48x48: 8x24 tiles, 128 couts)
+    (64, 48, 128, 64, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),     # dgrad of L2.conv1 (48x48, 64 couts)
+    (64, 24, 128, 256, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),    # L3.conv1 (24x24)
+    (16, 48, 128, 128, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),    # a smaller batch: 64-cout tile
     (64, 96, 64, 64, 1, "conv_mfma<TH=8,TW=8,S=2,NT=4,MODE=1>"),       # L1.downsample
     (64, 48, 128, 128, 1, "conv_mfma<TH=8,TW=8,S=2,NT=4,MODE=1>"),     # L2.downsample
     (64, 96, 128, 128, 1, "conv_mfma<TH=8,TW=8,S=2,NT=8,MODE=1>"),     # stride 2, 128-cout tile (2304 workgroups)
@@ -86,6 +89,7 @@ CONV_DGRAD = [
     (64, 96, 128, 128, "pool2", "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=0>"),   # dgrad of L4.upsample.conv (2x2-pooled)
     (64, 48, 128, 128, "zi", "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=3>"),      # dgrad of a stride-2 conv -> 96x96
     (64, 48, 64, 64, "zi", "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=3>"),        # dgrad of L1.downsample
+    (64, 24, 128, 128, "zi", "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=3>"),       # dgrad of L2.downsample -> 48x48
 ]
 
 
