@@ -13,8 +13,8 @@
 // in 144 accumulator registers per lane, and sweeps a strided subset of the spatial tiles
 // (split-K).  The input patch (with halo) is staged once per tile and re-read for all 9 taps.
 // Partials go to a per-workgroup fp32 slab in fragment order (16-byte coalesced stores); a
-// second kernel sums the slabs (split-K range cut into a few groups, one fp32 atomic per group and
-// element) into the fp32 gradient in the reference's OIHW layout.  The bias gradient
+// second kernel sums the slabs in a fixed order (no atomics: gradients are bit-reproducible) into the
+// fp32 gradient in the reference's OIHW layout.  The bias gradient
 // rides along as one extra MFMA per k-step against an all-ones operand.
 //
 // Reference semantics replaced: autograd's weight/bias gradients of nn.Conv2d / nn.Linear
@@ -245,63 +245,78 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 }
 
 // dw[(co*K + ci)*taps + tap] += sum_split slab[...]; dbias[co] += ...
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int nsplit, int ncot, int ncit, int taps, int Kreal,
-                                    int Nreal) {
-  // grid.x walks the accumulator elements, grid.y cuts the split-K range into groups so that
-  // enough independent loads are in flight to stream the slabs at HBM rate; each group folds
-  // its partial into dw with one hardware fp32 atomic per element.
+// Deterministic (bit-reproducible) reduction, one launch, no atomics: a 1024-thread block owns Q = 1024 / L
+// consecutive accumulator quads; its L "slab lanes" each sum a strided subset of the split-K slabs (four independent
+// 16-byte loads in flight per thread, runs of Q * 16 coalesced bytes), and the first Q threads add the L partial sums
+// in lane order before the single read-modify-write of dw.  L follows the split count (64+ slabs: L = 16; the few
+// slabs of a large gradient: L = 4), so every shape has enough loads in flight.  The blocks behind
+// the accumulator range do the same for the bias column (64 channels x 16 slab lanes).
+template <int L>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, int nsplit, int ncot, int ncit,
+                                                            int taps, int Kreal, int Nreal, int nblk_main) {
+  constexpr int Q = 1024 / L;
+  __shared__ f32x4 red[1024];
   const long slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
   const long per_tile = (long)taps * 4 * 4 * 256;
-  const long total4 = (long)ncot * ncit * per_tile / 4;  // one thread = the 4 accumulator registers of a lane
-  const int per_group = (nsplit + gridDim.y - 1) / gridDim.y;
-  const int sp0 = blockIdx.y * per_group;
-  const int sp1 = min(nsplit, sp0 + per_group);
   const long sp_stride = (long)ncot * ncit * slab_floats;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const long tile = i / (per_tile / 4);
-    const int e = (int)(i % (per_tile / 4)) * 4;
-    const int cot = (int)(tile / ncit), cit = (int)(tile % ncit);
-    const int lane = (e >> 2) & 63, wave = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
-    const int co = cot * 64 + t * 16 + (lane >> 4) * 4;
-    const int ci = cit * 64 + wave * 16 + (lane & 15);
-    if (co >= Nreal || ci >= Kreal) continue;
-    const float* src = slab + ((long)cot * ncit + cit) * slab_floats + e;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nblk_main) {
+    const int ql = tid % Q, sl = tid / Q;
+    const long total4 = (long)ncot * ncit * per_tile / 4;  // one quad = the 4 accumulator registers of an MFMA lane
+    const long i = (long)blockIdx.x * Q + ql;
+    const bool in = i < total4;
+    const long tile = in ? i / (per_tile / 4) : 0;
+    const int e = in ? (int)(i % (per_tile / 4)) * 4 : 0;
+    const float* src = slab + tile * slab_floats + e;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int sp = sp0;
-    for (; sp + 4 <= sp1; sp += 4) {
-      s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
-      s1 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 1) * sp_stride);
-      s2 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 2) * sp_stride);
-      s3 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 3) * sp_stride);
-    }
-    for (; sp < sp1; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
-    const f32x4 sum = (s0 + s1) + (s2 + s3);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (co + r >= Nreal) break;
-      float* dst = dw + ((long)(co + r) * Kreal + ci) * taps + tap;
-      if (gridDim.y == 1) *dst += sum[r]; else unsafeAtomicAdd(dst, sum[r]);
-    }
-  }
-  if (dbias) {
-    const long totalb = (long)ncot * 64;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < totalb; i += (long)gridDim.x * blockDim.x) {
-      const int cot = (int)(i / 64), cl = (int)(i % 64);
-      const int co = cot * 64 + cl;
-      if (co >= Nreal) continue;
-      const int t = cl >> 4, q = (cl & 15) >> 2, reg = cl & 3;
-      const int e = (t * 64 + q * 16) * 4 + reg;  // lane = q*16 (column 0)
-      const float* src = slab + ((long)cot * ncit) * slab_floats + per_tile + e;
-      float s0 = 0.f, s1 = 0.f;
-      int sp = sp0;
-      for (; sp + 2 <= sp1; sp += 2) {
-        s0 += src[(long)sp * sp_stride];
-        s1 += src[(long)(sp + 1) * sp_stride];
+    if (in) {
+      int sp = sl;
+      for (; sp + 3 * L < nsplit; sp += 4 * L) {
+        s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
+        s1 += *reinterpret_cast<const f32x4*>(src + (long)(sp + L) * sp_stride);
+        s2 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 2 * L) * sp_stride);
+        s3 += *reinterpret_cast<const f32x4*>(src + (long)(sp + 3 * L) * sp_stride);
       }
-      if (sp < sp1) s0 += src[(long)sp * sp_stride];
-      if (gridDim.y == 1) dbias[co] += s0 + s1; else unsafeAtomicAdd(dbias + co, s0 + s1);
+      for (; sp < nsplit; sp += L) s0 += *reinterpret_cast<const f32x4*>(src + (long)sp * sp_stride);
     }
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && in) {
+      f32x4 sum = red[ql];
+#pragma unroll 4
+      for (int w = 1; w < L; ++w) sum += red[w * Q + ql];
+      const int cot = (int)(tile / ncit), cit = (int)(tile % ncit);
+      const int ln = (e >> 2) & 63, wv = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
+      const int co = cot * 64 + t * 16 + (ln >> 4) * 4;
+      const int ci = cit * 64 + wv * 16 + (ln & 15);
+      if (ci < Kreal) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < Nreal) dw[((long)(co + r) * Kreal + ci) * taps + tap] += sum[r];
+      }
+    }
+    return;
+  }
+  // bias column: 64 channels per block, 16 slab lanes
+  const int cot = (int)blockIdx.x - nblk_main, cl = tid & 63, sl = tid >> 6;
+  const int co = cot * 64 + cl;
+  const int t = cl >> 4, q = (cl & 15) >> 2, reg = cl & 3;
+  const float* src = slab + ((long)cot * ncit) * slab_floats + per_tile + (t * 64 + q * 16) * 4 + reg;  // lane q*16 = column 0
+  float s0 = 0.f, s1 = 0.f;
+  int sp = sl;
+  for (; sp + 16 < nsplit; sp += 32) {
+    s0 += src[(long)sp * sp_stride];
+    s1 += src[(long)(sp + 16) * sp_stride];
+  }
+  if (sp < nsplit) s0 += src[(long)sp * sp_stride];
+  red[tid] = f32x4{s0 + s1, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (sl == 0 && co < Nreal) {
+    float sum = red[cl][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) sum += red[w * 64 + cl][0];
+    dbias[co] += sum;
   }
 }
 
@@ -393,18 +408,17 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   if (rc != DM_OK) return rc;
   const int Nreal = a->n_valid > 0 ? a->n_valid : a->Cout;
   const int Kreal = a->k_valid > 0 ? a->k_valid : a->Cin;
-  const long total = (long)pl.ncot * pl.ncit * a->taps * 1024;  // float4 items
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  // Split groups trade load parallelism against memory-side fp32 atomics (one per group and element), whose
-  // cost grows with the element count: measured best is a budget of about 300 k atomics per launch.
-  const long elems = (long)pl.ncot * pl.ncit * a->taps * 4096;
-  int groups = (int)(300000 / elems);
-  if (groups > 32) groups = 32;  // small 1x1 layers: short per-thread load chains matter more than the atomics
-  if (groups > pl.nsplit / 8) groups = pl.nsplit / 8;
-  if (groups < 1) groups = 1;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, groups), dim3(256), 0, st, (const float*)a->workspace, a->dw, a->dbias,
-                     pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal);
+  const long total4 = (long)pl.ncot * pl.ncit * a->taps * 1024;  // accumulator quads
+  // slab lanes per block (measured, tools/convbench.py: 64 lanes were no faster than 16 on the 512-slab shapes)
+  const int L = pl.nsplit >= 64 ? 16 : 4;
+  const int Q = 1024 / L;
+  const int nblk_main = (int)((total4 + Q - 1) / Q);
+  const int nblk = nblk_main + (a->dbias ? pl.ncot : 0);
+#define DM_RED(LL)                                                                                               \
+  hipLaunchKernelGGL(wgrad_reduce_kernel<LL>, dim3(nblk), dim3(1024), 0, st, (const float*)a->workspace, a->dw, \
+                     a->dbias, pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal, nblk_main)
+  if (L == 16) DM_RED(16); else DM_RED(4);
+#undef DM_RED
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -118,7 +118,9 @@ typedef struct dm_wgrad_args {
 } dm_wgrad_args;
 long dm_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode);
 /* Weight (and bias) gradient of the convolutions / linears above: split-K MFMA with
- * transposed LDS reads, deterministic two-stage reduction.  Replaces autograd's
+ * transposed LDS reads, deterministic two-stage reduction (partial slabs summed in a fixed order, no atomics:
+ * the same inputs give the same bits; dw / dbias are read-modify-written, so two calls that target the same dw
+ * must be stream-ordered).  Replaces autograd's
  * conv/linear weight-gradient for scaled_loss.backward() (main_stl10.py:502-503). */
 int dm_wgrad(const dm_wgrad_args* args, dm_stream_t stream);
 

@@ -165,6 +165,10 @@ def test_wgrad_conv_full_size(K, B, H, Cin, Cout, mode, variant):
     assert K.last_variant() == variant
     assert_close(dw - 1.0, gw, 5e-3, f"wgrad {variant}")
     assert_close(db - 1.0, gb, 5e-3, "bias grad")
+    # the split-K slabs are summed in a fixed order (no atomics): a second run gives the same bits
+    dw2, db2 = torch.ones_like(gw), torch.ones(Cout, device=dev())
+    K.wgrad(nhwc(x), nhwc(dy), dw2, db2, taps=9, mode=mode)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
 @pytest.mark.parametrize("M,Kd,N", [(589824, 128, 64), (589824, 64, 64), (147456, 256, 128), (147456, 128, 384)])
@@ -176,6 +180,9 @@ def test_wgrad_linear_full_size(K, M, Kd, N):
     assert K.last_variant() == "wgrad<TH=8,TW=16,S=1,MODE=4,TAPS=1>"
     assert_close(dw, (dy.double().t() @ x.double()).float(), 5e-3, "linear wgrad")
     assert_close(db, dy.double().sum(0).float(), 5e-3, "linear bias grad")
+    dw2, db2 = torch.zeros(N, Kd, device=dev()), torch.zeros(N, device=dev())
+    K.wgrad(x.to(torch.bfloat16), dy.to(torch.bfloat16), dw2, db2, taps=1)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)   # bit-reproducible
 
 
 def test_side_stream_workspace_growth_keeps_gradients(K):
