@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latent", action="store_true", help="skip the secondary latent-diffusion UNet leg (1 GPU only)")
     ap.add_argument("--no-elided", action="store_true", help="skip the secondary legs (dropout 0, dead-attention elided)")
+    ap.add_argument("--no-mnist", action="store_true", help="skip the MNIST small-shape leg (configs[4]; 1 GPU only)")
+    ap.add_argument("--graph", action="store_true", help="run the headline steps as HIP-graph replays (single GPU)")
     return ap.parse_args()
 
 
@@ -126,6 +128,58 @@ def latent_leg(a, dev, table, sched):
     dd = time.perf_counter() - t1
     out["dpm_solver_pp_2m_50_steps"] = {"value": S / dd, "unit": "latents/s", "finite": bool(torch.isfinite(xd).all().item())}
     return out
+
+
+def mnist_leg(a, dev):
+    """configs[4]: the reference's MNIST baseline (main.py:142-197: attention-free UNet, 32x32x1 = 28x28 padded by 2,
+    B=64, epsilon target, Adam 5e-5, clip 0.5, EMA 0.999, dropout 0.1, one optimizer step per batch) on synthetic
+    digits.  Every kernel of this configuration is tiny, so the step is bound by launch latency: timed once as eager
+    launches and once with the micro-step replayed as ONE HIP graph (Trainer.enable_graph)."""
+    from diffusion_model_amd import main as M
+    from diffusion_model_amd.ema import ModelEmaV2
+    from diffusion_model_amd.trainer import Trainer
+    from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+    torch.manual_seed(0)
+    model = M.build_model()
+    with torch.no_grad():
+        model.output_conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(1))
+    model = model.to(dev).train()
+    sched = DDPM_beta_t_cosine_scheduler(M.NUM_TIME_STEPS, beta_min=0.0)
+    tr = Trainer(model, sched, lr=M.LR, weight_decay=0.0, betas=(0.9, 0.999), clip=M.GRAD_CLIP, ema_decay=M.EMA_DECAY,
+                 accum=1, total_steps=0, low_t_weight=None, target="e", adamw=False, ema=ModelEmaV2(model, M.EMA_DECAY))
+    g = torch.Generator().manual_seed(99)
+    B = M.BATCH_SIZE
+    batches = [((torch.nn.functional.pad(torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, (2, 2, 2, 2))).to(dev), None,
+                torch.randint(0, M.NUM_TIME_STEPS, (B,), generator=g).to(dev),
+                torch.randn(B, 1, 32, 32, generator=g).to(dev)) for _ in range(4)]
+    n = max(20, 5 * a.steps)
+
+    def run(k):
+        loss = None
+        for i in range(k):
+            loss = tr.micro_step(*batches[i % 4])
+        return loss
+
+    def timed():
+        run(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = run(n)
+        t_host = time.perf_counter() - t0     # host time to ISSUE n steps (no sync inside)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, t_host / n, float(loss.item())
+
+    dt_e, host_e, loss_e = timed()
+    tr.enable_graph(*batches[0])
+    dt_g, host_g, loss_g = timed()
+    tr.disable_graph()
+    return {"what": "configs[4]: reference main.py MNIST baseline UNet (3.05 M parameters, no attention), 32x32x1, "
+                    "B=64, dropout 0.1, Adam + clip 0.5 + EMA, synthetic digits; step = one optimizer step",
+            "steps": n, "value": B / dt_g, "unit": "img/s",
+            "eager": {"ms_per_step": dt_e * 1e3, "host_issue_ms_per_step": host_e * 1e3, "img_per_s": B / dt_e,
+                      "final_loss": loss_e},
+            "hip_graph": {"ms_per_step": dt_g * 1e3, "host_issue_ms_per_step": host_g * 1e3, "img_per_s": B / dt_g,
+                          "final_loss": loss_g}}
 
 
 def time_conv_kernel(B, dev, H=48, cin=128, cout=128, mode=2, reps=20):
@@ -290,6 +344,11 @@ def main():
     for _ in range(a.warmup):
         opt_step()
     barrier()
+    if a.graph and world == 1:
+        tr.enable_graph(*batches[0])
+        for _ in range(2):
+            opt_step()
+        barrier()
     # roofline leg: HIP events around every launch of the dominant MFMA kernel (nearest-x2 + conv3x3 at the
     # L4.upsample.conv shape) INSIDE the timed steps, on the stream it is launched on
     from diffusion_model_amd import kernels as K
@@ -303,6 +362,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     K.PROBE = None
+    if a.graph and world == 1:
+        tr.disable_graph()
     if world > 1:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -451,6 +512,10 @@ def main():
         out["sampling"] = sampling
     if world == 1 and not a.no_latent and not a.no_elided:
         out["latent_unet"] = latent_leg(a, dev, table, sched)
+    if world == 1 and not a.no_mnist:
+        out["mnist"] = mnist_leg(a, dev)
+    if a.graph:
+        out["config"]["launch"] = "micro-step replayed as one HIP graph"
     if not a.no_roofline:
         iso_sec, fl, variant = time_conv_kernel(a.batch, dev)
         sec = iso_sec

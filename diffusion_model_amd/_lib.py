@@ -58,6 +58,8 @@ _SIGS = {
     "dm_last_hip_error": (C.c_char_p, []),
     "dm_note_hip_error": (None, [c_int]),
     "dm_last_variant": (C.c_char_p, []),
+    "dm_set_dropout_counter": (c_int, [c_void_p]),
+    "dm_bump_dropout_counter": (c_int, [c_void_p, c_void_p]),
     "dm_packed_weight_bytes": (c_long, [c_int, c_int, c_int]),
     "dm_pack_weights_batch": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "dm_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

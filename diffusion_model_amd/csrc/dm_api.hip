@@ -25,3 +25,23 @@ DmVariantName::DmVariantName(const char* fmt, ...) {
   vsnprintf(s, sizeof(s), fmt, ap);
   va_end(ap);
 }
+
+// Device-side dropout counter (see dm_common.h: dm_eff_seed).  Library-global on purpose: every kernel that draws a
+// dropout mask must see the same counter within one micro-step (forward and backward regenerate the same masks).
+static const uint32_t* g_drop_ctr = nullptr;
+const uint32_t* dm_dropout_counter() { return g_drop_ctr; }
+extern "C" int dm_set_dropout_counter(const unsigned int* dev_counter) {
+  g_drop_ctr = dev_counter;
+  return DM_OK;
+}
+namespace {
+__global__ void bump_counter_kernel(unsigned int* c) {
+  if (threadIdx.x == 0) c[0] = c[0] + 1u;
+}
+}  // namespace
+extern "C" int dm_bump_dropout_counter(unsigned int* dev_counter, dm_stream_t stream) {
+  DM_REQUIRE(dev_counter);
+  hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

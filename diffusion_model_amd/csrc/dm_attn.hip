@@ -36,6 +36,7 @@ struct AttnParams {
   int B, H, Nq, Nk, hd;
   float scale;
   uint32_t seed; uint32_t thresh; float inv_keep;  // dm_common.h dropout convention; thresh = 2*t15
+  const uint32_t* seed_ctr;                        // device-side seed counter (graph replay) or null
   uint32_t t15, tm1x2; float keep;  // flash kernels: 15-bit threshold, (t15-1) in both halves, 1-p
 };
 
@@ -178,6 +179,7 @@ __device__ __forceinline__ f32x4 score_mfma(bf16x8 a, bf16x8 b0, bf16x8 b1, f32x
 // select code, which the eval path then pays for.
 template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];  // dropout column words of the staged key block
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   for (int qt = 0; qt < 2; ++qt) {
     qi[qt] = q0 + qt * 16 + li;
     load_scaled_frag<DT>(p.q, p.ldq, qbase + qi[qt], qi[qt] < p.Nq, hoff, p.hd, g, c, qf0[qt], qf1[qt]);
-    if constexpr (DROP) rs[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
+    if constexpr (DROP) rs[qt] = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
   }
   float m[2] = {0.f, 0.f};  // reference maximum (exp2 domain), set by the first block
   // row sums of P ride on the MFMA pipe too: an all-ones A operand makes every row of lacc the sum over the
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   r1 = r0;
   if (nkb > 1) stage_load<DT>(r1, stg, 1);
   stage_store<DT>(r0, sKb[0], sVb[0], tid);
-  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
+  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(seed_eff, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
     if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
     if (kb + 1 < nkb) {
       stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
-      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
+      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(seed_eff, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
 // delta[bh][q] = sum_d dO[q][d] * O[q][d].  thread = (token, 8 channels): coalesced 16-byte loads of whole rows,
 // the hd/8 threads of a head combine with shuffles.
 __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ, sub = p.hd >> 3;
   const int tid = threadIdx.x, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
   const long rows = (long)p.B * p.Nq;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const AttnParams p
 }
 // generic shapes: thread = (batch, head, query)
 __global__ void attn_delta_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   const long total = (long)p.B * p.H * p.Nq;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % p.Nq);
@@ -382,6 +386,7 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 // the 1/keep rides in the dK epilogue, delta*keep in the dP accumulator's start value.
 template <int DT, bool DROP>
 __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];  // -LSE*log2e, -delta*keep
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   // this lane's 15-bit column field, in the low half; the row words come from the matching half-array of sRb
   uint32_t cwl = 0u;
   if constexpr (DROP) {
-    const uint32_t cw = dm_attn_colword(p.seed, (uint32_t)key >> 1) & M15;
+    const uint32_t cw = dm_attn_colword(seed_eff, (uint32_t)key >> 1) & M15;
     cwl = (key & 1) ? (cw >> 16) : cw;
   }
   const int rpar = (key & 1) * 64;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
       const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
       r.l = ok ? -lv : -1e30f;  // out-of-range query: p = exp2(-huge) = 0
       r.d = ok ? -dv * keepf : 0.f;
-      if (DROP) r.rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) & M15;
+      if (DROP) r.rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q)) & M15;
     }
   };
   auto put = [&](int buf, const Regs& r) {
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
 // dQ: mirrors the forward (one wave = 32 queries, workgroup = 128 queries, loop over key blocks of 64).
 template <int DT, bool DROP, bool EDGE>
 __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   __shared__ __attribute__((aligned(16))) char sKb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sVb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) uint32_t sCb[2][32];
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
     dof[qt] = load_row_frag(p.d_o, p.lddo, qbase + qi[qt], ok, hoff, p.hd, g);
     Lq[qt] = ok ? -p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : -1e30f;  // out-of-range query: p = 0
     Dq[qt] = ok ? -p.delta[(long)bh * p.Nq + qi[qt]] * keepf : 0.f;
-    if constexpr (DROP) rsq[qt] = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
+    if constexpr (DROP) rsq[qt] = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi[qt])) & M15;
   }
   f32x4 dqT[DT][2];
 #pragma unroll
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
   r1 = r0;
   if (nkb > 1) stage_load<DT>(r1, stg, 1);
   stage_store<DT>(r0, sKb[0], sVb[0], tid);
-  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(p.seed, (uint32_t)tid) & M15;
+  if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(seed_eff, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
     if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
     }
     if (kb + 1 < nkb) {
       stage_store<DT>(r_next, sKb[(kb + 1) & 1], sVb[(kb + 1) & 1], tid);
-      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(p.seed, (uint32_t)((kb + 1) * 32 + tid)) & M15;
+      if (DROP && wave == 0 && tid < 32) sCb[(kb + 1) & 1][tid] = dm_attn_colword(seed_eff, (uint32_t)((kb + 1) * 32 + tid)) & M15;
     }
     __syncthreads();
   };
@@ -632,6 +638,7 @@ constexpr int SMALL_CHUNKS = 8;  // query chunks (of 256/H queries) per block
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int H = p.H, C = H * HD, Nk = p.Nk, QB = 256 / H;
   float* sK = sm; float* sV = sK + Nk * C; float* sP = sV + Nk * C;
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const AttnParams p)
       const float inv = 1.f / l;
       const int bh = b * H + h;
       if (p.lse) p.lse[(long)bh * p.Nq + q] = m + __logf(l);
-      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) : 0u;
+      const uint32_t rs = p.thresh ? dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q)) : 0u;
 #pragma unroll
       for (int k = 0; k < SMALL_NK; ++k)
         if (k < Nk) {
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const AttnParams p)
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const AttnParams p, float* __restrict__ ws) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int H = p.H, C = H * HD, Nk = p.Nk, QB = 256 / H;
   float* sK = sm; float* sV = sK + Nk * C; float* sDS = sV + Nk * C; float* sPD = sDS + QB * H * Nk;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const AttnParams p,
       }
       const int bh = b * H + h;
       const float L = p.lse[(long)bh * p.Nq + q];
-      const uint32_t rs = p.thresh ? dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q)) : 0u;
+      const uint32_t rs = p.thresh ? dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q)) : 0u;
       float pk[SMALL_NK], dP[SMALL_NK];
       float delta = 0.f;
 #pragma unroll
@@ -790,6 +798,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const AttnParams p,
 }
 
 __global__ void attn_small_finish_kernel(const AttnParams p, const float* __restrict__ ws, int C) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   const long n = (long)p.B * p.Nk * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -864,6 +873,7 @@ __device__ __forceinline__ void wide_store_row(bf16* base, const float (&f)[HD /
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   constexpr int DPT = HD / 8;
   __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
   __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
@@ -876,7 +886,7 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) 
 #pragma unroll
   for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
   float m = NEG, l = 0.f;  // finite sentinel: the library is built with -ffast-math (no infinities)
-  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+  const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q));
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();
     wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
@@ -925,6 +935,7 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) 
 // dQ: the forward's mapping; P is rebuilt from the saved log-sum-exp.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   constexpr int DPT = HD / 8;
   __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
   __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p
   for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
   const float L = q_ok ? p.lse[(long)bh * p.Nq + q] : 0.f;
   const float dl = q_ok ? p.delta[(long)bh * p.Nq + q] : 0.f;
-  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+  const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q));
   for (int k0 = 0; k0 < p.Nk; k0 += 32) {
     __syncthreads();
     wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
@@ -977,6 +988,7 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p
 // dK, dV: thread = (key, eighth of the head); queries and their dO rows staged 32 at a time.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   constexpr int DPT = HD / 8;
   __shared__ __attribute__((aligned(16))) bf16 sQ[32 * HD];
   __shared__ __attribute__((aligned(16))) bf16 sD[32 * HD];
@@ -1016,7 +1028,7 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams 
       const float pj = qi < p.Nq ? __expf(sc - sL[i0 + part]) : 0.f;
       float zf = 1.f;
       if (p.thresh) {
-        const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + qi));
+        const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi));
         zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
       }
       const float ds = pj * (zf * dp - sDl[i0 + part]), pz = pj * zf;
@@ -1043,11 +1055,12 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams 
 // (Z: dropout mask of the one probability per (query, head), same words as the few-token kernels).  These are
 // pure streaming kernels: thread = (query, 8 channels), one 16-byte load and one 16-byte store per element
 // group, no LDS in the loop.
-__device__ __forceinline__ bool onekey_keep(const AttnParams& p, int bh, int q) {
-  const uint32_t rs = dm_drop_row(p.seed, (uint32_t)(bh * p.Nq + q));
+__device__ __forceinline__ bool onekey_keep(const AttnParams& p, uint32_t seed_eff, int bh, int q) {
+  const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q));
   return dm_keep16(dm_drop_bits(rs, 0u), 0u, p.thresh);
 }
 __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
   const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
   const int sub = p.hd >> 3;  // threads per head: 1, 2, 4, 8 or 16
@@ -1073,13 +1086,14 @@ __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p
       for (int o2 = 1; o2 < sub; o2 <<= 1) s += __shfl_xor(s, o2, 64);
       if ((tid % sub) == 0) p.lse[(long)bh * p.Nq + q] = s;
     }
-    const bool keep = !drop || onekey_keep(p, bh, q);
+    const bool keep = !drop || onekey_keep(p, seed_eff, bh, q);
     *reinterpret_cast<bf16x8*>(p.o + row * p.ldo + c8) = keep ? (drop ? vs : vr) : vz;
   }
 }
 // ws: [gridDim.x][B][C] fp32 per-block partial sums of dV (plain stores: no memset before, no atomics, a fixed
 // summation order), summed by attn_onekey_finish_kernel
 __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p, float* __restrict__ ws) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   __shared__ float sAcc[256 * 8];
   const int C = p.H * p.hd, TPQ = C >> 3, QPB = 256 / TPQ;
   const int tid = threadIdx.x, b = blockIdx.y, c8 = (tid % TPQ) * 8, qs = tid / TPQ, h = c8 / p.hd;
@@ -1092,7 +1106,7 @@ __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p
   for (int q = blockIdx.x * QPB + qs; q < p.Nq; q += gridDim.x * QPB) {
     const long row = (long)b * p.Nq + q;
     const bf16x8 d = *reinterpret_cast<const bf16x8*>(p.d_o + row * p.lddo + c8);
-    if (!drop || onekey_keep(p, bh, q)) {
+    if (!drop || onekey_keep(p, seed_eff, bh, q)) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += (float)d[j];
     }
@@ -1108,6 +1122,7 @@ __global__ __launch_bounds__(256) void attn_onekey_bwd_kernel(const AttnParams p
   }
 }
 __global__ void attn_onekey_finish_kernel(const AttnParams p, const float* __restrict__ ws, int C, int nblk) {
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
   const long n = (long)p.B * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -1148,6 +1163,7 @@ int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   p.dk = (bf16*)a->dk; p.lddk = a->lddk; p.dv = (bf16*)a->dv; p.lddv = a->lddv; p.delta = a->delta;
   p.B = a->B; p.H = a->heads; p.Nq = a->Nq; p.Nk = a->Nk; p.hd = a->hd; p.scale = a->scale;
   p.seed = dm_seed32(a->drop_seed);
+  p.seed_ctr = a->drop_p > 0.f ? dm_dropout_counter() : nullptr;
   // attention draws 15-bit fields (the flash kernels compare them with packed 16-bit signed arithmetic)
   uint32_t t15 = a->drop_p > 0.f ? (uint32_t)((double)a->drop_p * 32768.0 + 0.5) : 0u;
   if (t15 > 32767u) t15 = 32767u;

@@ -91,6 +91,13 @@ __device__ __forceinline__ bool dm_keep16(uint32_t bits32, uint32_t col, uint32_
   // 16-bit field (col & 1) of bits32 >= thresh16, compared in the high half (no field extraction)
   return ((col & 1u) ? bits32 : (bits32 << 16)) >= (thresh16 << 16);
 }
+// Dropout seeds under HIP-graph replay: a captured launch replays its kernel arguments, so a host-side seed alone
+// would repeat the same mask on every replay.  Kernels therefore add a DEVICE counter (dm_set_dropout_counter; the
+// caller bumps it once per micro-step, dm_bump_dropout_counter) to the hashed host seed.  NULL = no counter.
+__device__ __forceinline__ uint32_t dm_eff_seed(uint32_t seed, const uint32_t* __restrict__ ctr) {
+  return ctr ? seed + ctr[0] * 0x9E3779B1u : seed;
+}
+const uint32_t* dm_dropout_counter();   // dm_api.hip: the registered device counter (or NULL)
 // host side of the same convention
 static inline uint32_t dm_thresh16(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
 static inline float dm_inv_keep(float p) { return p > 0.f ? 65536.0f / (65536.0f - (float)dm_thresh16(p)) : 1.f; }

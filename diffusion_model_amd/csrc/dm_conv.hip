@@ -50,6 +50,7 @@ struct ConvParams {
   int act_silu_in;               // apply SiLU to the input while staging
   // dropout on the output (after bias/chan_add, before res): keep iff rng>=thresh, scale
   uint32_t drop_seed; uint32_t drop_thresh; float drop_scale;  // dm_common.h dropout convention
+  const uint32_t* seed_ctr;      // device-side seed counter (graph replay) or null
 };
 
 // Epilogue shared by the conv and the streaming GEMM kernels: lane holds couts [cq..cq+3] of pixel
@@ -88,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
         }
         if (!ok) pix = 0;
         uint32_t rs = 0u;
-        if (p.drop_thresh) rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
+        if (p.drop_thresh) rs = dm_drop_row(dm_eff_seed(p.drop_seed, p.seed_ctr), (uint32_t)pix);
 #pragma unroll
         for (int nt = 0; nt < NT; nt += 2) {
           u32x2 pk[2];
@@ -188,7 +189,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
       f32x4 v = acc[mt][nt] + bias4;
       if (p.chan_add) v += *reinterpret_cast<const f32x4*>(p.chan_add + (long)bb * p.Cout + co);
       if (p.drop_thresh) {
-        const uint32_t rs = dm_drop_row(p.drop_seed, (uint32_t)pix);
+        const uint32_t rs = dm_drop_row(dm_eff_seed(p.drop_seed, p.seed_ctr), (uint32_t)pix);
         const uint32_t b0 = dm_drop_bits(rs, (uint32_t)co >> 1), b1 = dm_drop_bits(rs, ((uint32_t)co >> 1) + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -708,7 +709,7 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
   p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
   p.pool2 = a->pool2; p.act_silu_in = a->act_silu_in;
-  p.drop_seed = dm_seed32(a->drop_seed); p.drop_scale = 1.0f;
+  p.drop_seed = dm_seed32(a->drop_seed); p.drop_scale = 1.0f; p.seed_ctr = dm_dropout_counter();
   p.drop_thresh = 0;
   if (a->drop_p > 0.f) {
     DM_REQUIRE(a->drop_p < 1.f);

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     long lddy, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
     const float* __restrict__ wsg, int nsplit, const bf16* __restrict__ add_in, long ldadd,
     bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
-    uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum) {
+    uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum, const uint32_t* __restrict__ seed_ctr) {
+  if (drop_thresh) drop_seed = dm_eff_seed(drop_seed, seed_ctr);
   __shared__ float s_s1[MAX_C], s_m1[64], s_m2[64];
   __shared__ float s_part[PART_LDS * 2];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -417,7 +418,7 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, wsg, ns, (const bf16*)add_in, ldadd, (bf16*)dx,
-                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum);
+                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum, dm_dropout_counter());
   DM_LAUNCH_CHECK();
   const int R = B * ns;
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, R < 16 ? R : 16), dim3(256), 0, st, ws, dgamma, dbeta,

@@ -63,6 +63,18 @@ def last_variant() -> str:
     return (_lib.lib().dm_last_variant() or b"").decode()
 
 
+def set_dropout_counter(counter: Optional[torch.Tensor]) -> None:
+    """Register (or, with None, unregister) the device counter every dropout kernel adds to its seed
+    (dm_set_dropout_counter): int32/uint32 tensor of one element that the caller keeps alive."""
+    if counter is not None and not (counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4):
+        raise ValueError("dropout counter: need a one-element 32-bit CUDA tensor")
+    check(_lib.lib().dm_set_dropout_counter(_p(counter)), "dm_set_dropout_counter")
+
+
+def bump_dropout_counter(counter: torch.Tensor) -> None:
+    check(_lib.lib().dm_bump_dropout_counter(_p(counter), _stream()), "dm_bump_dropout_counter")
+
+
 # --------------------------------------------------------------------------- workspace
 _WS = {}
 _WS_RETIRED = []   # outgrown side-stream buffers, kept alive until join_side() (see workspace())
@@ -218,6 +230,7 @@ def _side_stream(device):
 
 
 _PENDING = []     # weight gradients waiting for the next fork: (x, dy, dw, dbias, kw)
+CAPTURE_KEEPALIVE = None   # a list while a HIP graph is being captured (Trainer.capture), else None
 SIDE_BATCH = 8    # hipStreamWaitEvent costs the host ~14 us: fork once per few weight gradients, not per call (8 measured best of 1..16)
 
 
@@ -245,8 +258,13 @@ def flush_side() -> None:
     finally:
         _FORCED_STREAM[0] = None
     for x, dy, _, _, _ in _PENDING:
-        x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
-        dy.record_stream(side)
+        if CAPTURE_KEEPALIVE is not None:
+            # under graph capture the operands live in the graph's private pool: keeping them referenced until the
+            # capture ends stops the allocator from handing their blocks out again inside the same graph
+            CAPTURE_KEEPALIVE.append((x, dy))
+        else:
+            x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
+            dy.record_stream(side)
     _PENDING.clear()
     _SIDE_DIRTY.add(dev.index or 0)
 

@@ -146,6 +146,7 @@ class Trainer:
         self.buckets = None
         self.pg = process_group
         self.last_skipped = False  # micro_step(check_finite=True) found a non-finite loss and skipped the batch
+        self._graph = self._gin = self._gloss = self._gctr = None   # enable_graph()
         if distributed:
             import torch.distributed as dist
             self.buckets = GradBuckets(self.fp, unet_stage_names(model), process_group)
@@ -171,6 +172,76 @@ class Trainer:
         invalidate_packed_weights()
 
     # ------------------------------------------------------------------ one micro-batch
+    def _loss_weights(self, B: int, chw: int, t: torch.Tensor) -> torch.Tensor:
+        if self.low_t_weight is None:
+            key = (B * chw, None, t.device)
+            if getattr(self, "_wflat_key", None) != key:
+                self._wflat = torch.full((B,), 1.0 / (B * chw), dtype=torch.float32, device=t.device)
+                self._wflat_key = key
+            return self._wflat
+        # exp(-k t) / (B chw) for every timestep once (the same elementwise ops the per-batch statement ran, so the
+        # rows are bit-identical): one gather per micro-batch instead of four small kernels
+        key = (B * chw, self.low_t_weight, t.device)
+        if getattr(self, "_wtab_key", None) != key:
+            steps = torch.arange(self.scheduler.alpha_t.numel(), device=t.device)
+            self._wtab, self._wtab_key = torch.exp(-self.low_t_weight * steps.float()) / (B * chw), key
+        return self._wtab[t]
+
+    def _micro_body(self, x, context, t, e):
+        """q-sample -> forward -> loss + dL/dout -> backward (weight gradients joined), all on device: the part of a
+        micro-step a HIP graph can hold.  Returns the loss tensor [1]."""
+        B = x.shape[0]
+        chw = x.numel() // B
+        if self._gctr is not None:
+            K.bump_dropout_counter(self._gctr)
+        xt, v = K.qsample_vtarget(x, e, self.scheduler.alpha_t[t].contiguous())
+        tgt = v if self.target == "v" else e
+        y, saved = self.model._fwd(xt, t, context)
+        loss, dout = K.mse_loss_fwd_bwd(y, tgt, self._loss_weights(B, chw, t).contiguous(), grad_scale=1.0 / self.accum)
+        self.model._bwd(dout, saved, self.grads, join=True)
+        return loss
+
+    def enable_graph(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, warmup: int = 3) -> None:
+        """Capture the micro-step (``_micro_body``) for inputs of this shape as ONE HIP graph; ``micro_step`` then
+        copies its arguments into the graph's static input buffers and replays it -- one host call instead of a few
+        hundred kernel launches (the launch-bound small-shape configurations: reference main.py, 32x32x1).  The
+        optimizer step stays eager (its scalars change every step).  Dropout masks still differ per replay: every
+        dropout kernel adds a device counter to its seed, bumped by the graph's first node (dm_set_dropout_counter).
+        Call at an accumulation boundary (the warm-up runs accumulate into the gradient buffer, which is re-zeroed);
+        single-process only (the data-parallel bucket hooks issue collectives from Python)."""
+        if self.buckets is not None and self.world > 1:
+            raise RuntimeError("enable_graph: not available under data parallelism")
+        if self.micro != 0:
+            raise RuntimeError("enable_graph: call at an accumulation boundary")
+        dev = x.device
+        self._gctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        K.set_dropout_counter(self._gctr)
+        self._gin = (x.clone(), None if context is None else context.clone(), t.clone(), e.clone())
+        self.model._bwd_hook = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # eager warm-up off the default stream (workspaces, packed weights, tables)
+            for _ in range(max(1, warmup)):
+                self._micro_body(*self._gin)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.fp.grad.zero_()
+        graph = torch.cuda.CUDAGraph()
+        K.CAPTURE_KEEPALIVE = []
+        try:
+            with torch.cuda.graph(graph):
+                self._gloss = self._micro_body(*self._gin)
+        finally:
+            K.CAPTURE_KEEPALIVE = None
+        self.fp.grad.zero_()                   # capture enqueues nothing, but keep the contract explicit
+        self._graph = graph
+
+    def disable_graph(self) -> None:
+        self._graph = None
+        self._gin = self._gloss = None
+        self._gctr = None
+        K.set_dropout_counter(None)
+
     def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, *,
                    step_now: Optional[bool] = None, check_finite: bool = False) -> torch.Tensor:
         """x,e: [B,C,H,W] fp32 on the device; t: [B] long (device); context: [B,D] fp32 or None.
@@ -178,23 +249,30 @@ class Trainer:
         step_now overrides the accumulation gate (reference main_stl10.py:506: the last batch of an epoch
         steps even if the accumulation window is not full); check_finite mirrors main_stl10.py:484-486
         (a non-finite loss skips the batch before backward) at the price of one host sync."""
+        last = ((self.micro + 1) % self.accum == 0) if step_now is None else bool(step_now)
+        if self._graph is not None and not check_finite and x.shape == self._gin[0].shape and \
+                (context is None) == (self._gin[1] is None):
+            gx, gc, gt, ge = self._gin
+            gx.copy_(x, non_blocking=True)
+            ge.copy_(e, non_blocking=True)
+            gt.copy_(t, non_blocking=True)
+            if gc is not None:
+                gc.copy_(context, non_blocking=True)
+            self._graph.replay()
+            self.last_skipped = False
+            self.micro = 0 if last else self.micro + 1
+            if last and not self.defer_optimizer:
+                self.optimizer_step()
+            return self._gloss
         B = x.shape[0]
         chw = x.numel() // B
+        if self._gctr is not None:
+            K.bump_dropout_counter(self._gctr)
         abar = self.scheduler.alpha_t[t].contiguous()
         xt, v = K.qsample_vtarget(x, e, abar)
         tgt = v if self.target == "v" else e
-        last = ((self.micro + 1) % self.accum == 0) if step_now is None else bool(step_now)
         y, saved = self.model._fwd(xt, t, context)
-        if self.low_t_weight is None:
-            w = torch.full((B,), 1.0 / (B * chw), dtype=torch.float32, device=x.device)
-        else:
-            # exp(-k t) / (B chw) for every timestep once (the same elementwise ops the per-batch statement ran, so the
-            # rows are bit-identical): one gather per micro-batch instead of four small kernels
-            key = (B * chw, self.low_t_weight, x.device)
-            if getattr(self, "_wtab_key", None) != key:
-                steps = torch.arange(self.scheduler.alpha_t.numel(), device=x.device)
-                self._wtab, self._wtab_key = torch.exp(-self.low_t_weight * steps.float()) / (B * chw), key
-            w = self._wtab[t]
+        w = self._loss_weights(B, chw, t)
         loss, dout = K.mse_loss_fwd_bwd(y, tgt, w.contiguous(), grad_scale=1.0 / self.accum)
         self.last_skipped = False
         if check_finite:

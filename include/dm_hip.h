@@ -45,6 +45,15 @@ void dm_note_hip_error(int code);
  * Test/diagnostic hook: no reference counterpart. */
 const char* dm_last_variant(void);
 
+/* Dropout under HIP-graph replay.  Every dropout site (nn.Dropout of the ResBlock, unet.py:76,105; the attention
+ * dropout_p of F.scaled_dot_product_attention, unet.py:136,214) takes its seed as a kernel ARGUMENT, which a captured
+ * graph replays unchanged.  When a device counter is registered here, every such kernel adds it to its (hashed) seed
+ * at run time, so the caller bumps it once per micro-step (dm_bump_dropout_counter: one tiny launch, capturable) and
+ * every replay draws fresh masks -- while the forward and backward of one micro-step still agree on them.
+ * dev_counter = NULL unregisters.  Library-global state: one process drives one GPU (one rank per GPU). */
+int dm_set_dropout_counter(const unsigned int* dev_counter);
+int dm_bump_dropout_counter(unsigned int* dev_counter, dm_stream_t stream);
+
 /* ------------------------------------------------------------------ weights */
 /* Bytes of the packed bf16 shadow of an [N][K][taps] weight (N padded to 16, K to 64). */
 long dm_packed_weight_bytes(int N, int K, int taps);
