@@ -23,7 +23,8 @@ class ConvArgs(C.Structure):
                 ("ldy", c_long), ("yf", c_void_p), ("ldyf", c_long),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
                 ("mode", c_int), ("n_valid", c_int), ("pool2", c_int), ("act_silu_in", c_int),
-                ("drop_p", c_float), ("drop_seed", c_ulonglong)]
+                ("drop_p", c_float), ("drop_seed", c_ulonglong),
+                ("norm_scale", c_void_p), ("norm_shift", c_void_p)]
 
 
 class GemmArgs(C.Structure):
@@ -39,7 +40,8 @@ class WgradArgs(C.Structure):
                 ("dw", c_void_p), ("dbias", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
                 ("taps", c_int), ("mode", c_int), ("act_silu_in", c_int), ("n_valid", c_int),
-                ("k_valid", c_int), ("workspace", c_void_p), ("ws_bytes", c_long)]
+                ("k_valid", c_int), ("workspace", c_void_p), ("ws_bytes", c_long),
+                ("norm_scale", c_void_p), ("norm_shift", c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -70,6 +72,8 @@ _SIGS = {
     "dm_gn_workspace_bytes": (c_long, [c_int] * 4),
     "dm_gn_silu_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
                                c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p]),
+    "dm_gn_prepare": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_int, c_int, c_float, c_void_p, c_long, c_void_p]),
     "dm_gn_silu_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p, c_long, c_void_p]),

@@ -48,6 +48,8 @@ struct ConvParams {
   int n_valid;                   // number of real output channels to store
   int pool2;                     // sum 2x2 output pixels (dgrad of nearest-x2)
   int act_silu_in;               // apply SiLU to the input while staging
+  const float* nsc; const float* nsh;  // [B][Cin] fp32 or null: stage silu(x * nsc + nsh) (GroupNorm + SiLU folded into
+                                       // the consumer: dm_gn_prepare supplies the per-(sample, channel) scale / shift)
   // dropout on the output (after bias/chan_add, before res): keep iff rng>=thresh, scale
   uint32_t drop_seed; uint32_t drop_thresh; float drop_scale;  // dm_common.h dropout convention
   const uint32_t* seed_ctr;      // device-side seed counter (graph replay) or null
@@ -219,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
   }
 }
 
-template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
+template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE, bool NORM = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   constexpr int TAPS = (MODE == MODE_GEMM) ? 1 : 9;
   constexpr int PH = (MODE == MODE_GEMM) ? TH : (MODE == MODE_Q8) ? 20 : ((S == 1) ? TH + 2 : 2 * TH + 1);
@@ -286,7 +288,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   constexpr int NPA = (A_PIECES + 255) / 256;
   const int G = ncc * NS;
 
+  static_assert(NPA <= 32, "validity bits of a thread's patch pieces live in one word");
+  uint32_t pmask = 0u;  // bit i: piece i of this thread lies inside the image (zero padding must stay zero after nsc/nsh)
   auto load_patch = [&](int cc, u32x4(&pa)[NPA]) {
+    pmask = 0u;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int idx = tid + i * 256;
@@ -322,9 +327,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       // unconditional load (offset 0 is always readable) so that all NPA loads are in flight together
       const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (valid ? src : 0));
       pa[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (NORM) pmask |= (valid ? 1u : 0u) << i;
     }
   };
-  auto store_patch = [&](u32x4(&pa)[NPA]) {
+  auto store_patch = [&](u32x4(&pa)[NPA], int cc) {
+    if constexpr (NORM) {
+      // the thread's pieces all hold channels [cc*64 + (tid&7)*8, +8) of sample b; four channels at a time
+      const long o = (long)b * p.Cin + cc * 64 + (tid & 7) * 8;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.nsc + o + 4 * hf);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.nsh + o + 4 * hf);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+          bf16x8 h = __builtin_bit_cast(bf16x8, pa[i]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[4 * hf + j] = (bf16)dm_silu((float)h[4 * hf + j] * sc[j] + sh[j]);
+          pa[i] = __builtin_bit_cast(u32x4, h);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NPA; ++i)
+        if (!((pmask >> i) & 1u)) pa[i] = u32x4{0u, 0u, 0u, 0u};   // zero padding stays zero
+    }
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const int idx = tid + i * 256;
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     load_patch(0, pa);
     load_b(0, br0);
     if (G > 1) load_b(1, br1);
-    store_patch(pa);
+    store_patch(pa, 0);
     store_b(0, br0);
   }
   __syncthreads();
@@ -404,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       u32x4 pa[NPA];
       load_patch(cc + 1, pa);
       __syncthreads();
-      store_patch(pa);
+      store_patch(pa, cc + 1);
       s = 0; ++cc;
     }
     if (g + 1 < G) store_b((g + 1) & 1, br_next);
@@ -418,14 +443,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   conv_epilogue<MT, NT, TW, MODE>(p, acc, nb, wave, lane, b, h0, w0, m0);
 }
 
-template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE>
+template <int TH, int TW, int S, int PITCH, int STRIDE, int NT, int MODE, bool NORM = false>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   constexpr int PH = (MODE == MODE_GEMM) ? TH : (MODE == MODE_Q8) ? 20 : ((S == 1) ? TH + 2 : 2 * TH + 1);
   constexpr int A_BYTES = ((PH * PITCH * STRIDE + 15) / 16) * 16;
   constexpr int KSPS = (NT <= 4) ? 2 : 1;
   constexpr int LDS = A_BYTES + 2 * KSPS * NT * 1024;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU must fit in 160 KiB of LDS");
-  auto k = conv_mfma_kernel<TH, TW, S, PITCH, STRIDE, NT, MODE>;
+  auto k = conv_mfma_kernel<TH, TW, S, PITCH, STRIDE, NT, MODE, NORM>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -436,7 +461,8 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   if (MODE == MODE_GEMM) grid = dim3((unsigned)((p.M + TH * TW - 1) / (TH * TW)), (unsigned)(p.Cout / (16 * NT)));
   else if (MODE == MODE_Q8) grid = dim3((unsigned)((p.B + 3) / 4), (unsigned)(p.Cout / (16 * NT)));
   else grid = dim3((unsigned)(p.B * p.tiles_h * p.tiles_w), (unsigned)(p.Cout / (16 * NT)));
-  static const DmVariantName vn("conv_mfma<TH=%d,TW=%d,S=%d,NT=%d,MODE=%d>", TH, TW, S, NT, MODE);
+  static const DmVariantName vn(NORM ? "conv_mfma<TH=%d,TW=%d,S=%d,NT=%d,MODE=%d,NORM>" : "conv_mfma<TH=%d,TW=%d,S=%d,NT=%d,MODE=%d>",
+                                TH, TW, S, NT, MODE);
   dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, grid, dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
@@ -709,6 +735,9 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
   p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout;
   p.pool2 = a->pool2; p.act_silu_in = a->act_silu_in;
+  DM_REQUIRE((a->norm_scale == nullptr) == (a->norm_shift == nullptr));
+  DM_REQUIRE(!a->norm_scale || (a->mode == 0 && !a->act_silu_in && !a->pool2));  // GroupNorm feeds plain 3x3 convs only
+  p.nsc = a->norm_scale; p.nsh = a->norm_shift;
   p.drop_seed = dm_seed32(a->drop_seed); p.drop_scale = 1.0f; p.seed_ctr = dm_dropout_counter();
   p.drop_thresh = 0;
   if (a->drop_p > 0.f) {
@@ -722,7 +751,7 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
   else if (mode == 2 || mode == 3) { p.Ho = a->H * 2; p.Wo = a->W * 2; }
   else { p.Ho = a->H; p.Wo = a->W; }
   DM_REQUIRE(!p.pool2 || (p.Ho % 2 == 0 && p.Wo % 2 == 0 && p.y && !p.yf && !p.res && !p.chan_add && !p.drop_thresh));
-  if (mode == 0 && a->H == 8 && a->W == 8 && a->B >= 4 && !p.pool2) {
+  if (mode == 0 && a->H == 8 && a->W == 8 && a->B >= 4 && !p.pool2 && !p.nsc) {
     // 8x8 images (the latent model's innermost stage: 4096 pixels against K*N up to 9216 x 1024): four images per
     // workgroup; 32-cout workgroups when the 64-cout grid would leave CUs idle
     const int quads = (a->B + 3) / 4;
@@ -754,6 +783,18 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
     return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE>(p, st);                      \
   } while (0)
   if (mode == 1) DM_GO(8, 8, 2, 24, 144, MODE_S2);
+#define DM_GON(TH, TW, S, PITCH, STRIDE)                                                      \
+  do {                                                                                      \
+    if (nt == 8) return launch_conv<TH, TW, S, PITCH, STRIDE, 8, MODE_S1, true>(p, st);     \
+    return launch_conv<TH, TW, S, PITCH, STRIDE, 4, MODE_S1, true>(p, st);                  \
+  } while (0)
+  if (p.nsc) {
+    // (the 16x16 x 128-cout tile has no registers left for the scale / shift rows: 64 couts there)
+    if (tile == 0) return launch_conv<16, 16, 1, 18, 160, 4, MODE_S1, true>(p, st);
+    if (tile == 1) DM_GON(8, 24, 1, 32, 160);
+    DM_GON(8, 8, 1, 10, 160);
+  }
+#undef DM_GON
   if (tile == 0) {
     if (mode == 0) DM_GO(16, 16, 1, 18, 160, MODE_S1);
     if (mode == 2) DM_GO(16, 16, 1, 18, 160, MODE_UP);

@@ -151,6 +151,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
   for (; pix < p_end; pix += ppi) one(*reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx), pix);
 }
 
+// grid (B): merge the sample's (split, group) partials -> stats[b][g] = {mean, rstd}; scale[b][c] = gamma*rstd,
+// shift[b][c] = beta + (chan_add - mean)*scale  (the affine a consumer applies in place of gn_apply_kernel)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nsplit,
+                                                           const float* __restrict__ chan_add,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ stats,
+                                                           float* __restrict__ scale, float* __restrict__ shift, int C,
+                                                           int G, float eps) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < G) {
+    Wf acc = {0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+      const float* o = partial + (((long)b * nsplit + s) * G + tid) * 3;
+      Wf w = {o[0], o[1], o[2]};
+      acc = wf_merge(acc, w);
+    }
+    const float rstd = rsqrtf(acc.m2 / acc.n + eps);
+    s_mean[tid] = acc.mean; s_rstd[tid] = rstd;
+    stats[((long)b * G + tid) * 2] = acc.mean; stats[((long)b * G + tid) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = gamma[c] * s_rstd[g];
+    const float a = chan_add ? chan_add[(long)b * C + c] : 0.f;
+    scale[(long)b * C + c] = sc;
+    shift[(long)b * C + c] = beta[c] + (a - s_mean[g]) * sc;   // the same expression gn_apply_kernel evaluates
+  }
+}
+
 // ---------------------------------------------------------------- backward
 // pass 1: grid (nsplit, B): ws[b][split][c] = { sum_p dz, sum_p dz*xhat }
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restrict__ x, long ldx,
@@ -394,6 +426,24 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
   DM_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add, gamma, beta,
                      (const float*)workspace, ns, stats, (bf16*)y, ldy, HW, C, G, eps, ns, act_silu);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_gn_prepare(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
+                             float* stats, float* scale, float* shift, int B, int HW, int C, int G, float eps,
+                             void* workspace, long ws_bytes, dm_stream_t stream) {
+  DM_REQUIRE(x && gamma && beta && stats && scale && shift && workspace);
+  DM_REQUIRE(C % 8 == 0 && C <= MAX_C && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0);
+  DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0);
+  DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G));
+  const int ns = pick_split(B, HW);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
+                     (float*)workspace, HW, C, G, ns);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, (const float*)workspace, ns, chan_add, gamma, beta,
+                     stats, scale, shift, C, G, eps);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

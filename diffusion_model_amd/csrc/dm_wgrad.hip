@@ -35,6 +35,7 @@ struct WgradParams {
   int tiles_h, tiles_w, ntiles, nsplit;
   long M;
   int act_silu_in;
+  const float* nsc; const float* nsh;  // [B][Cin] fp32 or null: the forward read silu(x * nsc + nsh) (dm_conv_args.norm_*)
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
@@ -46,7 +47,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS>
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
   constexpr int PW = (MODE == WM_GEMM) ? TW : ((S == 1) ? TW + 2 : 2 * TW + 1);
@@ -94,6 +95,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int NPD = (NPIX * 8 + 255) / 256;
   static_assert((NPIX * 8) % 256 == 0, "dy tile pieces must divide evenly over the workgroup");
 
+  static_assert(NPX <= 32, "validity bits of a thread's x pieces live in one word");
+  uint32_t xmask = 0u;   // NORM: bit i = piece i of the fetched x patch lies inside the image (padding stays zero)
+  int xb = 0;            // NORM: sample of the fetched x patch (row of the scale / shift tables)
   auto load_tile = [&](int tile, u32x4(&px)[NPX], u32x4(&pd)[NPD], bool do_x, bool do_d) {
     int b = 0, h0 = 0, w0 = 0;
     long m0 = 0;
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     const int vh0 = (MODE == WM_S2) ? 2 * h0 - 1 : h0 - 1;
     const int vw0 = (MODE == WM_S2) ? 2 * w0 - 1 : w0 - 1;
+    if (do_x) { xmask = 0u; xb = b; }
     if (do_x)
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       }
       const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (valid ? src : 0));  // offset 0 is readable
       px[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
+      if constexpr (NORM) xmask |= (valid ? 1u : 0u) << i;
     }
     if (do_d)
 #pragma unroll
@@ -159,6 +165,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
   };
   auto store_tile = [&](u32x4(&px)[NPX], u32x4(&pd)[NPD], bool do_x, bool do_d) {
+    if constexpr (NORM) {
+      if (do_x) {
+        // the thread's pieces all hold channels [cit*64 + (tid&7)*8, +8) of sample xb; four channels at a time
+        // (the kernel has no registers to spare next to its 160 accumulators)
+        const long o = (long)xb * p.Cin + cit * 64 + (tid & 7) * 8;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.nsc + o + 4 * hf);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.nsh + o + 4 * hf);
+#pragma unroll
+          for (int i = 0; i < NPX; ++i) {
+            bf16x8 h = __builtin_bit_cast(bf16x8, px[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[4 * hf + j] = (bf16)dm_silu((float)h[4 * hf + j] * sc[j] + sh[j]);
+            px[i] = __builtin_bit_cast(u32x4, h);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NPX; ++i)
+          if (!((xmask >> i) & 1u)) px[i] = u32x4{0u, 0u, 0u, 0u};   // zero padding stays zero
+      }
+    }
     if (do_x)
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
@@ -351,20 +379,21 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
   return pl;
 }
 
-template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS>
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false>
 int launch_wgrad(const WgradParams& p, const Plan& pl, hipStream_t st) {
   constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
   constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
   constexpr int LDS = X_BYTES + TH * TW * DYS;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS>;
+  auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS, NORM>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
     attr_set = true;
   }
-  static const DmVariantName vn("wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>", TH, TW, S, MODE, TAPS);
+  static const DmVariantName vn(NORM ? "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d,NORM>" : "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>",
+                                TH, TW, S, MODE, TAPS);
   dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, dim3(pl.nsplit, pl.ncot, pl.ncit), dim3(256), LDS, st, p);
   DM_LAUNCH_CHECK();
@@ -395,8 +424,16 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   p.tiles_h = (p.Ho + pl.th - 1) / pl.th; p.tiles_w = (p.Wo + pl.tw - 1) / pl.tw; p.ntiles = pl.ntiles; p.nsplit = pl.nsplit;
   p.M = (long)a->B * a->H * a->W;
   p.act_silu_in = a->act_silu_in;
+  DM_REQUIRE((a->norm_scale == nullptr) == (a->norm_shift == nullptr));
+  DM_REQUIRE(!a->norm_scale || (a->taps == 9 && a->mode == 0 && !a->act_silu_in));
+  p.nsc = a->norm_scale; p.nsh = a->norm_shift;
   hipStream_t st = (hipStream_t)stream;
   int rc = DM_ERR_ARG;
+  if (p.nsc) {
+    if (pl.tw == 16) rc = launch_wgrad<8, 16, 1, 18, 160, WM_S1, 9, true>(p, pl, st);
+    else if (pl.tw == 24) rc = launch_wgrad<8, 24, 1, 26, 160, WM_S1, 9, true>(p, pl, st);
+    else rc = launch_wgrad<8, 8, 1, 10, 160, WM_S1, 9, true>(p, pl, st);
+  } else
   if (a->taps == 1) rc = launch_wgrad<8, 16, 1, 16, 160, WM_GEMM, 1>(p, pl, st);
   else if (a->mode == 1) rc = launch_wgrad<8, 8, 2, 17, 144, WM_S2, 9>(p, pl, st);
   else if (pl.tw == 16) rc = (a->mode == 0) ? launch_wgrad<8, 16, 1, 18, 160, WM_S1, 9>(p, pl, st)

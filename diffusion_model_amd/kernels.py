@@ -127,7 +127,9 @@ PROBE = None
 
 
 def conv3x3(x, wp, cout, *, bias=None, chan_add=None, res=None, out=None, mode=0, pool2=False,
-            act_silu_in=False, drop_p=0.0, drop_seed=0, out_f32=None, n_valid=0):
+            act_silu_in=False, drop_p=0.0, drop_seed=0, out_f32=None, n_valid=0, norm_in=None):
+    """norm_in = (scale, shift) from gn_prepare: the conv reads silu(x * scale + shift), i.e. SiLU(GroupNorm(x)),
+    while staging its input -- the normalised activation is never materialised."""
     B, H, W, Cin = x.shape
     ldx = _act(x, "x")
     Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode in (2, 3) else (H, W))
@@ -150,6 +152,10 @@ def conv3x3(x, wp, cout, *, bias=None, chan_add=None, res=None, out=None, mode=0
     a.B, a.H, a.W, a.Cin, a.Cout = B, H, W, Cin, cout
     a.mode, a.n_valid, a.pool2, a.act_silu_in = mode, n_valid, int(pool2), int(act_silu_in)
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    if norm_in is not None:
+        sc, sh = norm_in
+        assert tuple(sc.shape) == (B, Cin) and tuple(sh.shape) == (B, Cin)
+        a.norm_scale, a.norm_shift = _p(_f32(sc, "norm scale")), _p(_f32(sh, "norm shift"))
     pr = PROBE
     if pr is not None and mode == pr["mode"] and H == pr["H"] and Cin == pr["cin"] and cout == pr["cout"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -185,8 +191,9 @@ def gemm(x, wp, n, *, bias=None, chan_add=None, rows_per_batch=0, res=None, out=
     return out if out is not None else out_f32
 
 
-def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0, k_valid=0):
-    """dw (fp32, reference layout) += dy^T * patches(x); dbias += column sums of dy."""
+def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0, k_valid=0, norm_in=None):
+    """dw (fp32, reference layout) += dy^T * patches(x); dbias += column sums of dy.  norm_in as in conv3x3: the
+    forward conv read silu(x * scale + shift)."""
     ldx, lddy = _act(x, "x"), _act(dy, "dy")
     _f32(dw, "dw"), _f32(dbias, "dbias")
     Cin, Cout = x.shape[-1], dy.shape[-1]
@@ -202,6 +209,8 @@ def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0
     a.B, a.H, a.W, a.Cin, a.Cout = B, H, W, Cin, Cout
     a.taps, a.mode, a.act_silu_in, a.n_valid, a.k_valid = taps, mode, int(act_silu_in), n_valid, k_valid
     a.workspace, a.ws_bytes = _p(ws), ws.numel()
+    if norm_in is not None:
+        a.norm_scale, a.norm_shift = _p(_f32(norm_in[0], "norm scale")), _p(_f32(norm_in[1], "norm shift"))
     check(L.dm_wgrad(C.byref(a), _stream()), "dm_wgrad")
 
 
@@ -257,14 +266,15 @@ def flush_side() -> None:
             wgrad(x, dy, dw, dbias, **kw)
     finally:
         _FORCED_STREAM[0] = None
-    for x, dy, _, _, _ in _PENDING:
+    for x, dy, _, _, kw in _PENDING:
+        held = (x, dy, *(kw.get("norm_in") or ()))
         if CAPTURE_KEEPALIVE is not None:
             # under graph capture the operands live in the graph's private pool: keeping them referenced until the
             # capture ends stops the allocator from handing their blocks out again inside the same graph
-            CAPTURE_KEEPALIVE.append((x, dy))
+            CAPTURE_KEEPALIVE.append(held)
         else:
-            x.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
-            dy.record_stream(side)
+            for t in held:
+                t.record_stream(side)   # the caching allocator must not recycle these before the side stream is done
     _PENDING.clear()
     _SIDE_DIRTY.add(dev.index or 0)
 
@@ -353,6 +363,23 @@ def gn_silu_fwd(x, gamma, beta, groups, *, chan_add=None, eps=1e-5, act=True, ou
                            _p(_f32(beta, "beta")), _p(out), _act(out, "out"), _p(stats), B, HW, Cc, groups,
                            eps, int(act), _p(ws), ws.numel(), _stream()), "dm_gn_silu_fwd")
     return out, stats
+
+
+def gn_prepare(x, gamma, beta, groups, *, chan_add=None, eps=1e-5):
+    """Statistics of GroupNorm(x) in one pass over x -> (stats [B,G,2] = {mean, rstd}, scale [B,C], shift [B,C]);
+    pass (scale, shift) as ``norm_in`` to conv3x3 / wgrad (dm_gn_prepare, include/dm_hip.h)."""
+    ldx = _act(x, "x")
+    Cc = x.shape[-1]
+    B = x.shape[0]
+    HW = x.numel() // (B * Cc)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    ss = torch.empty((2, B, Cc), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    ws = workspace(L.dm_gn_workspace_bytes(B, HW, Cc, groups), x.device)
+    check(L.dm_gn_prepare(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(_f32(gamma, "gamma")), _p(_f32(beta, "beta")),
+                          _p(stats), _p(ss[0]), _p(ss[1]), B, HW, Cc, groups, eps, _p(ws), ws.numel(), _stream()),
+          "dm_gn_prepare")
+    return stats, (ss[0], ss[1])
 
 
 def gn_silu_bwd(x, dy, gamma, beta, stats, groups, dgamma, dbeta, *, chan_add=None, add_in=None, act=True,

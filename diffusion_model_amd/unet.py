@@ -246,6 +246,15 @@ class SinusoidalEmbeddings(nn.Module):
         return self.embeddings[t]
 
 
+# GroupNorm + SiLU folded into the consuming convolution (dm_gn_prepare + dm_conv_args.norm_scale/shift; bit-identical
+# values: the conv prologue evaluates the very expression the apply kernel evaluates).  OFF by default -- measured
+# (tools/normfold_bench.py, B=64, profiles/r02_normfold.txt): the forward pair gains (L1: 109.7 -> 102.7 us, no
+# normalised tensor written) but every consumer re-evaluates exp + rcp for its halo and once per 64-cout block, which
+# costs the conv +12 us and the weight gradient +19 us at that shape: a net loss for training.  DM_FOLD_GROUPNORM=1
+# turns it on (less activation memory, one pass over x in the forward).
+FOLD_GROUPNORM = [os.environ.get("DM_FOLD_GROUPNORM", "0") == "1"]
+
+
 class ResBlock(HipModule):
     """Reference unet.py:70-108."""
 
@@ -271,25 +280,43 @@ class ResBlock(HipModule):
         B = x.shape[0]
         tp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
         K.gemm(temb, PW.of(lin).fwd, self.cout, bias=_b(lin), act_silu_in=True, out_f32=tp)
-        g1, st1 = K.gn_silu_fwd(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
         p = self.p if self.training else 0.0
         seed = next(_SEED) if p > 0 else 0
-        h = K.conv3x3(g1, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1), chan_add=tp, drop_p=p, drop_seed=seed)
-        g2, st2 = K.gn_silu_fwd(h, self.norm2.weight.detach(), self.norm2.bias.detach(), self.groups)
+        # GroupNorm + SiLU are folded into the consuming conv (FOLD_GROUPNORM): one statistics pass over the input,
+        # then the conv normalises while staging its patch; the normalised tensor is never written.  (8x8 images of
+        # a batch >= 4 keep the materialised form: their four-images-per-workgroup conv tile has no folded variant.)
+        fold = FOLD_GROUPNORM[0] and not (x.shape[1] == 8 and x.shape[2] == 8 and B >= 4)
+        if fold:
+            st1, n1 = K.gn_prepare(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
+            h = K.conv3x3(x, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1), chan_add=tp, drop_p=p,
+                          drop_seed=seed, norm_in=n1)
+            st2, n2 = K.gn_prepare(h, self.norm2.weight.detach(), self.norm2.bias.detach(), self.groups)
+            g1 = g2 = None
+        else:
+            n1 = n2 = None
+            g1, st1 = K.gn_silu_fwd(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
+            h = K.conv3x3(g1, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1), chan_add=tp, drop_p=p, drop_seed=seed)
+            g2, st2 = K.gn_silu_fwd(h, self.norm2.weight.detach(), self.norm2.bias.detach(), self.groups)
         if isinstance(self.skip, nn.Identity):
             sk = x
         else:
             sk = K.gemm(x, PW.of(self.skip).fwd, self.cout, bias=_b(self.skip))
-        y = K.conv3x3(g2, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out)
-        return y, (x, temb, g1, st1, h, g2, st2, p, seed)
+        if fold:
+            y = K.conv3x3(h, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out, norm_in=n2)
+        else:
+            y = K.conv3x3(g2, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out)
+        return y, (x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed)
 
     def _bwd(self, dy, saved, g: Grads, dts=None, need_dx=True):
         """Returns (dx, dts): dts = accumulated gradient wrt silu(temb), bf16 [B, temb_dim]."""
-        x, temb, g1, st1, h, g2, st2, p, seed = saved
+        x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed = saved
         B = x.shape[0]
         lin = self.time_mlp[1]
         d_g2 = K.conv3x3(dy, PW.of(self.conv2).bwd, self.cout)
-        K.wgrad_side(g2, dy, g.of(self.conv2.weight), g.of(self.conv2.bias))
+        if g2 is None:   # folded GroupNorm: the weight gradient re-normalises h while staging, as the forward conv did
+            K.wgrad_side(h, dy, g.of(self.conv2.weight), g.of(self.conv2.bias), norm_in=n2)
+        else:
+            K.wgrad_side(g2, dy, g.of(self.conv2.weight), g.of(self.conv2.bias))
         if isinstance(self.skip, nn.Identity):
             dsk = dy
         else:
@@ -306,7 +333,10 @@ class ResBlock(HipModule):
             dts = d_this
         else:  # fp32 accumulation across the ResBlocks (batchsum with one "batch" row == axpy)
             K.batchsum(d_this.view(1, -1), dts.view(-1))
-        K.wgrad_side(g1, dh, g.of(self.conv1.weight), None)
+        if g1 is None:
+            K.wgrad_side(x, dh, g.of(self.conv1.weight), None, norm_in=n1)
+        else:
+            K.wgrad_side(g1, dh, g.of(self.conv1.weight), None)
         dx = None
         if need_dx:
             d_g1 = K.conv3x3(dh, PW.of(self.conv1).bwd, self.cin)

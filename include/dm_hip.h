@@ -90,6 +90,8 @@ typedef struct dm_conv_args {
   int act_silu_in;                /* apply SiLU to the input while staging */
   float drop_p;                   /* dropout on (conv+bias+chan_add) before the residual add */
   unsigned long long drop_seed;
+  const float* norm_scale;        /* [B,Cin] fp32 or NULL: the conv reads silu(x * norm_scale + norm_shift) -- GroupNorm + */
+  const float* norm_shift;        /* SiLU folded into the consumer (dm_gn_prepare); zero padding stays zero */
 } dm_conv_args;
 /* Implicit-GEMM 3x3 convolution on bf16 MFMA, LDS-staged input halo.
  * Replaces: nn.Conv2d 3x3 (unet.py:74-75,234,317-319), F.interpolate(nearest x2)+conv
@@ -124,6 +126,8 @@ typedef struct dm_wgrad_args {
   int act_silu_in;                /* forward applied SiLU to x while staging */
   int n_valid, k_valid;           /* real Cout / Cin to write into dw (0 = all) */
   void* workspace; long ws_bytes; /* >= dm_wgrad_workspace_bytes */
+  const float* norm_scale;        /* as dm_conv_args.norm_scale / norm_shift: the forward conv read */
+  const float* norm_shift;        /* silu(x * norm_scale + norm_shift) (taps = 9, mode 0 only) */
 } dm_wgrad_args;
 long dm_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode);
 /* Weight (and bias) gradient of the convolutions / linears above: split-K MFMA with
@@ -141,6 +145,15 @@ long dm_gn_workspace_bytes(int B, int HW, int C, int G);
 int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
                    void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
                    void* workspace, long ws_bytes, dm_stream_t stream);
+/* GroupNorm folded into its consumer: statistics of x (+ chan_add) per (sample, group) in ONE pass over x, then
+ * stats[b][g] = {mean, rstd} and the per-(sample, channel) affine  scale = gamma * rstd,
+ * shift = beta + (chan_add - mean) * scale  ([B][C] fp32 each), so that a convolution given norm_scale / norm_shift
+ * reads silu(x * scale + shift) = SiLU(GroupNorm(x)) while staging its input patch -- the normalised activation is
+ * never written to memory (4 -> 2 bytes per element for the forward GroupNorm; unet.py:94,106 feeding :95,107).
+ * Same constraints and workspace as dm_gn_silu_fwd. */
+int dm_gn_prepare(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
+                  float* stats, float* scale, float* shift, int B, int HW, int C, int G, float eps,
+                  void* workspace, long ws_bytes, dm_stream_t stream);
 /* dx = d/dx of the above (+ add_in), optional dropout mask (the mask dm_conv3x3 applied to x);
  * dgamma/dbeta accumulated (+=).  dx_colsum (optional, [B][C] fp32, accumulated +=): per-sample channel sums
  * of the written dx = the gradient of the time-embedding projection / conv1 bias of the ResBlock

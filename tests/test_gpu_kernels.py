@@ -428,3 +428,38 @@ def test_batchsum2_cast(K):
         o3 = torch.zeros(C, device=dev())
         assert K.batchsum2_cast(x, o3, None, want_bf16=False) is None
         assert_close(o3, x.sum(0), 1e-5, "out1 alone")
+
+
+# ------------------------------------------------------------------ GroupNorm folded into the consuming conv
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 20, 36, 128, 64), (2, 12, 12, 64, 128),
+                                            (3, 24, 24, 256, 256), (1, 48, 48, 128, 128), (5, 8, 8, 64, 64)])
+def test_groupnorm_folded_into_conv_and_wgrad(K, B, H, W, Cin, Cout):
+    """dm_gn_prepare + dm_conv_args.norm_scale/shift: the conv stages silu(x*scale + shift) itself.  Must equal the
+    materialised path (dm_gn_silu_fwd, then the conv on its output) bit for bit -- same expression, same rounding --
+    zero padding included, and the torch statement of GroupNorm -> SiLU -> conv within the bf16 tolerance."""
+    x = q16(rnd(B, Cin, H, W, seed=1) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(Cin, seed=2), 0.1 * rnd(Cin, seed=3)
+    w = rnd(Cout, Cin, 3, 3, seed=4, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd(Cout, seed=5, scale=0.1)
+    xq, wp = nhwc(x), K.pack_weight(w)
+    g_mat, stats_mat = K.gn_silu_fwd(xq, gamma, beta, 8)
+    y_mat = K.conv3x3(g_mat, wp, Cout, bias=bias)
+    stats, nin = K.gn_prepare(xq, gamma, beta, 8)
+    y_fold = K.conv3x3(xq, wp, Cout, bias=bias, norm_in=nin)
+    assert "NORM" in K.last_variant()
+    assert torch.equal(stats, stats_mat)
+    assert torch.equal(y_fold, y_mat)
+    ref = F.conv2d(q16(F.silu(F.group_norm(x, 8, gamma, beta, 1e-5))), q16(w), bias, padding=1)
+    assert_close(nchw(y_fold), ref, BF, "folded GroupNorm conv vs torch")
+    dy = nhwc(q16(rnd(B, Cout, H, W, seed=6)))
+    dw_mat, db_mat = torch.zeros(Cout, Cin, 3, 3, device=dev()), torch.zeros(Cout, device=dev())
+    K.wgrad(g_mat, dy, dw_mat, db_mat)
+    dw_fold, db_fold = torch.zeros_like(dw_mat), torch.zeros_like(db_mat)
+    K.wgrad(xq, dy, dw_fold, db_fold, norm_in=nin)
+    assert "NORM" in K.last_variant()
+    assert torch.equal(dw_fold, dw_mat) and torch.equal(db_fold, db_mat)
+    # with a per-(sample, channel) pre-add (the time-embedding form of dm_gn_silu_fwd)
+    ca = rnd(B, Cin, seed=7)
+    g2, _ = K.gn_silu_fwd(xq, gamma, beta, 8, chan_add=ca)
+    _, nin2 = K.gn_prepare(xq, gamma, beta, 8, chan_add=ca)
+    assert torch.equal(K.conv3x3(xq, wp, Cout, norm_in=nin2), K.conv3x3(g2, wp, Cout))
