@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-elided", action="store_true", help="skip the secondary legs (dropout 0, dead-attention elided)")
     ap.add_argument("--no-mnist", action="store_true", help="skip the MNIST small-shape leg (configs[4]; 1 GPU only)")
     ap.add_argument("--graph", action="store_true", help="run the headline steps as HIP-graph replays (single GPU)")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="1 GPU: run the data-parallel code path (RCCL process group of ONE rank, bucket all-reduces "
+                         "issued from the backward hooks) -- a rehearsal of the N>1 path, not a scaling number")
     return ap.parse_args()
 
 
@@ -315,6 +318,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    elif a.rehearse_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from diffusion_model_amd.ema import ModelEmaV2
     from diffusion_model_amd.sampler import CFGSampler
@@ -327,7 +334,9 @@ def main():
     ema = ModelEmaV2(model, decay=0.995)
     tr = Trainer(model, sched, lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99), clip=1.0, ema_decay=0.995,
                  accum=2, total_steps=100 * 79, start_step=20 * 40, low_t_weight=0.01, ema=ema,
-                 distributed=world > 1)
+                 distributed=world > 1 or a.rehearse_dp)
+    if a.rehearse_dp and tr.buckets is not None:
+        tr.buckets.force = True
     batches = [synth_batch(a.batch, rank * 2 + i, dev, table, sched) for i in range(2)]
 
     def opt_step():
@@ -547,8 +556,8 @@ def main():
         out["roofline"]["other_conv_kernels_back_to_back"] = others
     if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
-    if world > 1:
+    print(json.dumps(out), flush=True)          # flushed before the process group is torn down
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

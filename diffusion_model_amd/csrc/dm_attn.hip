@@ -390,7 +390,11 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
   __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];  // -LSE*log2e, -delta*keep
-  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][128];  // per-query dropout row words: [0..63] as is, [64..127] >> 16
+  // per-query dropout row words: [0..63] as is, [ROFF..ROFF+63] >> 16.  ROFF = 72 (not 64): the lanes of one
+  // ds_read_b128 group read the even-key and the odd-key half at the same query offset; 64 dwords apart they hit the
+  // same banks (2-way conflict on every row-word read: 13 % of this kernel's LDS cycles in round 1's PMC run)
+  constexpr int ROFF = 72;
+  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][ROFF + 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   const int gk = DT == 1 ? (g & 1) : g;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
     const uint32_t cw = dm_attn_colword(seed_eff, (uint32_t)key >> 1) & M15;
     cwl = (key & 1) ? (cw >> 16) : cw;
   }
-  const int rpar = (key & 1) * 64;
+  const int rpar = (key & 1) * ROFF;
   const float keepf = DROP ? p.keep : 1.f;
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
   const Stager<DT> stg = make_stager<DT>(p.q, p.ldq, p.d_o, p.lddo, qbase, p.Nq, hoff, p.hd, tid, wave);
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
     stage_store<DT>(r.st, sQb[buf], sOb[buf], tid);
     if (wave == 0) {
       sLb[buf][tid] = r.l; sDb[buf][tid] = r.d;
-      if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][64 + tid] = r.rs >> 16; }
+      if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][ROFF + tid] = r.rs >> 16; }
     }
   };
   Regs r0{}, r1{};

@@ -91,9 +91,10 @@ class GradBuckets:
             covered += sum(b - a for a, b in r)
         assert covered == fp.total, "every parameter must belong to exactly one bucket"
         self.pending = []
+        self.force = False
 
     def launch(self, stage: str) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.force:   # (force: rehearse the collective path on one rank, bench --rehearse-dp)
             return
         for a, b in self.stage_ranges[stage]:
             self.pending.append(self.dist.all_reduce(self.fp.grad[a:b], op=self.dist.ReduceOp.SUM,
