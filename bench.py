@@ -533,7 +533,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # collected in separate rocprofv3 --pmc runs of the same kernel and shape; bench.py cannot run PMC itself)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_conv.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_dominant_conv.json")
         if a.batch == 64 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes"]
         out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
