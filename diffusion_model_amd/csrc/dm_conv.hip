@@ -43,6 +43,7 @@ struct ConvParams {
   float* yf; long ldyf;          // optional fp32 output
   int B, Hi, Wi, Cin, Cout, Ho, Wo;
   int tiles_h, tiles_w;
+  int ntiles;                    // conv_ws_kernel: tiles along grid.x's walk (set by launch_conv_ws)
   long M;                        // GEMM mode: rows
   int rows_per_batch;            // GEMM mode: rows per chan_add batch index
   int n_valid;                   // number of real output channels to store
@@ -469,6 +470,262 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   return DM_OK;
 }
 
+// ------------------------------------------------------------------ wave-specialised persistent 3x3 conv
+// Why: ablation of conv_mfma_kernel (profiles/r02_conv_ablation.txt) shows a SERIAL time budget -- for the 64->64 layer at
+// 96x96, B=64: k-loop ~39 us + halo-patch fetch ~13 us + epilogue ~14 us = 66 us.  The fetch and the epilogue are
+// HBM phases (the layer moves 170 MB: 27 us at the achievable 6.3 TB/s, against 17 us of MFMA at peak -- it is an
+// HBM-roofline layer) and nothing overlaps them with the k-loop: a wave's vmcnt counter retires IN ORDER, so a patch
+// prefetch or the epilogue's stores issued by a wave that also streams the weight stages block that wave's next weight
+// wait until they are done; two co-resident workgroups do not hide it for each other either (staggering them changes
+// nothing: a lone workgroup's k-loop is latency-bound and runs at half the pair's rate).
+// So the roles get their own waves, i.e. their own vmcnt counters, inside one PERSISTENT workgroup of six waves:
+//   waves 0-3  consumers: LDS -> MFMA k-loop and the epilogue.  They never wait on vmcnt in the loop, so a tile's
+//              stores drain while the next tile's taps already run;
+//   wave 4     weight loader: streams the packed weight stages global -> registers -> LDS double buffer, two stages
+//              ahead, straight through tile boundaries (the stages repeat with period G);
+//   wave 5     patch loader: holds the NEXT unit's (tile, 64-channel chunk) halo patch in its registers while the
+//              current unit runs and writes it to LDS at the unit boundary.
+// All six waves meet at one barrier per weight stage plus one per unit boundary.  Tile 8x24 output pixels (three
+// m-tiles per consumer wave) so that the loader's patch fits its registers and the whole kernel stays under 168 VGPRs:
+// three waves per SIMD, two workgroups (12 waves) per CU.
+struct ConvWalk {   // this workgroup's walk over its (tile, channel-chunk) units
+  int t_cur, t_nxt, tstride, ntiles, cc, ncc;
+  __device__ bool has_next() const { return cc + 1 < ncc || t_nxt < ntiles; }
+  __device__ bool tile_end() const { return cc + 1 == ncc; }
+  __device__ void next(int& t, int& c) const {
+    if (cc + 1 < ncc) { t = t_cur; c = cc + 1; } else { t = t_nxt; c = 0; }
+  }
+  __device__ void advance() {
+    if (cc + 1 < ncc) { ++cc; } else { t_cur = t_nxt; t_nxt += tstride; cc = 0; }
+  }
+};
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(512, 4) void conv_ws_kernel(const ConvParams p) {
+  constexpr int TH = 8, TW = 24, PH = TH + 2, PW = TW + 2, PITCH = PW, STRIDE = 144, MT = 3;
+  constexpr int A_BYTES = PH * PITCH * STRIDE;        // 37,440
+  constexpr int KSPS = 2;                             // k-steps (of 32) per weight stage
+  constexpr int B_STAGE = KSPS * NT * 1024;
+  constexpr int NS = 9;                               // stages per 64-channel chunk (one tap each)
+  constexpr int A_PIECES = PH * PW * 8;               // 16-byte pieces of a patch
+  constexpr int NPA = (A_PIECES + 127) / 128;         // per lane of a patch loader wave (two of them)
+  constexpr int NPB = B_STAGE / 16 / 128;             // per lane of a weight loader wave (two of them)
+  static_assert(MODE == MODE_S1 || MODE == MODE_UP || MODE == MODE_ZI, "stride-1 family only");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = blockIdx.y;
+  const int NTG = p.Cout >> 4;
+  const int ncc = (p.Cin + 63) >> 6;
+  const int G = ncc * NS;
+
+  ConvWalk wk;
+  wk.t_cur = blockIdx.x; wk.tstride = gridDim.x; wk.t_nxt = blockIdx.x + gridDim.x;
+  wk.ntiles = p.ntiles; wk.cc = 0; wk.ncc = ncc;
+  auto decode = [&](int t, int& b, int& h0, int& w0) {
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h;
+    b = t / p.tiles_h; h0 = th_i * TH; w0 = tw_i * TW;
+  };
+
+  if (wave < 4) {
+    // ================================================================= consumers
+    int aoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int q = (wave * MT + mt) * 16 + (lane & 15);
+      const int r = q / TW, c = q % TW;
+      aoff[mt] = (r * PITCH + c) * STRIDE + (lane >> 4) * 16;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int gbuf = 0;
+    __syncthreads();   // first patch and weight stage 0 are in LDS
+    for (;;) {
+      for (int s = 0; s < NS; ++s) {
+        const char* sBc = sB + gbuf * B_STAGE;
+        const int kh = (s * 11) >> 5, kw = s - 3 * kh;   // tap s: (s / 3, s % 3)
+#pragma unroll
+        for (int ksl = 0; ksl < KSPS; ++ksl) {
+          const int tapoff = (kh * PITCH + kw) * STRIDE + ksl * 64;
+          bf16x8 av[MT], bv[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            av[mt] = *reinterpret_cast<const bf16x8*>(sA + aoff[mt] + tapoff);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            bv[nt] = *reinterpret_cast<const bf16x8*>(sBc + (ksl * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[nt], av[mt], acc[mt][nt], 0, 0, 0);
+        }
+        gbuf ^= 1;
+        __syncthreads();   // stage barrier
+      }
+      if (wk.tile_end()) {
+        int b, h0, w0;
+        decode(wk.t_cur, b, h0, w0);
+        conv_epilogue<MT, NT, TW, MODE>(p, acc, nb, wave, lane, b, h0, w0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!wk.has_next()) break;
+      __syncthreads();     // unit barrier: the patch loader has swapped the patch
+      wk.advance();
+    }
+  } else if (wave < 6) {
+    // ================================================================= weight loaders (each half a stage)
+    const int l2 = lane + (wave - 4) * 64;
+    const char* wbase = p.w + ((long)nb * NT * 64) * 16;
+    auto load_b = [&](int g, u32x4(&br)[NPB]) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        const int piece = l2 + i * 128;
+        const int ksl = piece / (NT * 64), rem = piece % (NT * 64);
+        br[i] = *reinterpret_cast<const u32x4*>(wbase + ((long)(g * KSPS + ksl) * NTG) * 1024 + rem * 16);
+      }
+    };
+    auto store_b = [&](int buf, u32x4(&br)[NPB]) {
+#pragma unroll
+      for (int i = 0; i < NPB; ++i)
+        *reinterpret_cast<u32x4*>(sB + buf * B_STAGE + (l2 + i * 128) * 16) = br[i];
+    };
+    // units of this workgroup -> number of stages it will run
+    const int nmine = (wk.ntiles - wk.t_cur + wk.tstride - 1) / wk.tstride;
+    const int total = nmine * G;
+    // ONE register set: during stage g it holds stage g + 1 (in flight since the top of stage g - 1's slot), is written
+    // to the LDS buffer stage g - 1 ran from, and is refilled with stage g + 2 right away -- a full stage of flight time
+    u32x4 bx[NPB];
+    load_b(0, bx);
+    store_b(0, bx);
+    load_b(1 % G, bx);
+    int gl = 2 % G;
+    __syncthreads();
+    int sc = 0;
+    for (int g = 0; g < total; ++g) {
+      store_b((g + 1) & 1, bx);            // stage g + 1 -> the buffer the consumers are NOT reading during stage g
+      load_b(gl, bx); gl = (gl + 1 == G) ? 0 : gl + 1;
+      __syncthreads();                     // stage barrier
+      if (++sc == NS) { sc = 0; if (g + 1 < total) __syncthreads(); }   // unit barrier
+    }
+  } else {
+    // ================================================================= patch loaders (each half the pieces)
+    const int l2 = lane + (wave - 6) * 64;
+    // Buffer loads: one descriptor per sample (uniform), a 32-bit byte offset per piece, and an out-of-range offset
+    // for the zero padding -- the hardware returns 0, so no validity masks or 64-bit addresses stay live next to the
+    // 132 registers the patch itself needs.
+    const int sample_bytes = (int)((((long)p.Hi * p.Wi - 1) * p.ldx + p.Cin) * 2);
+    auto load_patch = [&](int t, int cc, u32x4(&pa)[NPA]) {
+      int b, h0, w0;
+      decode(t, b, h0, w0);
+      const int vh0 = h0 - 1, vw0 = w0 - 1;
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (long)b * p.Hi * p.Wi * p.ldx), 0, sample_bytes, 0x00020000);
+      const int ldb = (int)p.ldx * 2;
+      // piece i of this lane: pixel (lane >> 3) + 8 i of the patch (row-major, PW wide), 16-byte piece lane & 7.  The
+      // walk is incremental and fenced per piece (sched_barrier), so that one offset is live at a time.
+      const int chb = (cc * 64 + (lane & 7) * 8) * 2;
+      int pr = 0, pc = l2 >> 3;
+      asm volatile("" : "+v"(pc));
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        bool valid = (A_PIECES % 128 == 0) || (pr < PH);
+        const int vh = vh0 + pr, vw = vw0 + pc;
+        int sh = vh, sw = vw;
+        if constexpr (MODE == MODE_UP) {
+          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+          sh = vh >> 1; sw = vw >> 1;
+        } else if constexpr (MODE == MODE_ZI) {
+          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi) && (((vh | vw) & 1) == 0);
+          sh = vh >> 1; sw = vw >> 1;
+        } else {
+          valid = valid && (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+        }
+        const int off = valid ? (sh * p.Wi + sw) * ldb + chb : 0x7ffffff0;
+        pa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        pc += 16;
+        if (pc >= PW) { pc -= PW; ++pr; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto store_patch = [&](u32x4(&pa)[NPA]) {
+      int pr = 0, pc = l2 >> 3;
+      asm volatile("" : "+v"(pc));
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        if ((A_PIECES % 128 == 0) || (pr < PH))
+          *reinterpret_cast<u32x4*>(sA + (pr * PITCH + pc) * STRIDE + (lane & 7) * 16) = pa[i];
+        pc += 16;
+        if (pc >= PW) { pc -= PW; ++pr; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    u32x4 pa[NPA];
+    load_patch(wk.t_cur, 0, pa);
+    store_patch(pa);
+    __syncthreads();
+    int tn, cn;
+    bool has = wk.has_next();
+    if (has) { wk.next(tn, cn); load_patch(tn, cn, pa); }
+    for (;;) {
+      for (int s = 0; s < NS; ++s) __syncthreads();   // the unit's stage barriers
+      if (!has) break;
+      store_patch(pa);     // every consumer is past the unit's last stage barrier: the old patch is dead
+      __syncthreads();     // unit barrier
+      wk.advance();
+      has = wk.has_next();
+      if (has) { wk.next(tn, cn); load_patch(tn, cn, pa); }
+    }
+  }
+}
+
+template <int NT, int MODE>
+int launch_conv_ws(const ConvParams& p0, hipStream_t st) {
+  constexpr int LDS = 10 * 26 * 144 + 2 * 2 * NT * 1024;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  auto k = conv_ws_kernel<NT, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  ConvParams p = p0;
+  const long ntiles = (long)p.B * p.tiles_h * p.tiles_w;
+  if (ntiles <= 0 || ntiles > 0x7fffffffL) return DM_ERR_ARG;
+  p.ntiles = (int)ntiles;
+  static int resident = 0;   // co-resident workgroups: two per CU (12 of the 16 wave slots; VGPRs allow no third)
+  if (!resident) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    resident = 2 * cus;
+    if (const char* f = getenv("DM_CONV_WS_RESIDENT")) resident = atoi(f);   // developer override
+  }
+  const int gy = p.Cout / (16 * NT);
+  int gx = resident / gy;
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  const int rounds = (p.ntiles + gx - 1) / gx;
+  gx = (p.ntiles + rounds - 1) / rounds;   // same number of rounds, evenly filled
+  static const DmVariantName vn("conv_ws<TH=8,TW=24,NT=%d,MODE=%d>", NT, MODE);
+  dm_set_variant(vn.s);
+  hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(512), LDS, st, p);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 // ------------------------------------------------------------------ streaming GEMM (1x1 conv / linear)
 // Y[M, N] = X[M, K] W^T with K <= 512: HBM-bound (X read once, Y written once), so the kernel is built
 // around the memory stream, not the MFMA pipe:
@@ -773,6 +1030,21 @@ extern "C" int dm_conv3x3(const dm_conv_args* a, dm_stream_t stream) {
     if (sscanf(f, "%d,%d", &ft, &fn) >= 1) {
       if (mode != 1 && !p.pool2 && ft >= 0 && ft <= 2) tile = ft;
       if ((fn == 4 || (fn == 8 && can128))) nt = fn;
+    }
+  }
+  // 64-cout tiles go to the wave-specialised persistent kernel when 8x24 tiles cover the image exactly (measured,
+  // tools/convbench.py, B=64: 64->64 @96x96 60.6 -> 55.8 us, 64->128 @48x48 34.2 -> 31.4 us, zero-insert dgrad 64->64
+  // 59.8 -> 54.9 us; with 128-cout tiles the 256-VGPR conv_mfma_kernel stays ahead: its accumulators do not fit the
+  // 128 registers that two eight-wave workgroups per CU leave each wave)
+  // ... and when every persistent workgroup gets at least two tiles to pipeline (a smaller launch is all prologue)
+  if (mode != 1 && nt == 4 && !p.pool2 && !p.nsc && !p.act_silu_in && p.Ho % 8 == 0 && p.Wo % 24 == 0 &&
+      (long)p.B * (p.Ho / 8) * (p.Wo / 24) * (a->Cout / 64) >= 1024) {
+    const char* f = getenv("DM_CONV_WS");   // developer switch: "0" = off
+    if (!f || f[0] != '0') {
+      p.tiles_h = p.Ho / 8; p.tiles_w = p.Wo / 24;
+      if (mode == 0) return launch_conv_ws<4, MODE_S1>(p, st);
+      if (mode == 2) return launch_conv_ws<4, MODE_UP>(p, st);
+      return launch_conv_ws<4, MODE_ZI>(p, st);
     }
   }
   static const int TH_[3] = {16, 8, 8}, TW_[3] = {16, 24, 8};

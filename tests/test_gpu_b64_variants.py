@@ -59,8 +59,10 @@ CONV_FWD = [
     (64, 48, 128, 128, 2, "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=2>"),   # L4.upsample.conv: bench.py's roofline kernel
     (64, 24, 256, 256, 2, "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=2>"),    # L3.upsample.conv (48x48 out: 8x24 tiles)
     (64, 96, 64, 128, 0, "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=0>"),    # dgrad of late_conv1 (128 <- 64 @ 96x96)
-    (64, 96, 64, 64, 0, "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"),     # L1.conv1/conv2, late_conv2: top of the profile
-    (64, 96, 128, 64, 0, "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"),    # late_conv1
+    (64, 96, 64, 64, 0, "conv_ws<TH=8,TW=24,NT=4,MODE=0>"),            # L1.conv1/conv2: top of the profile (wave-specialised)
+    (64, 96, 128, 64, 0, "conv_ws<TH=8,TW=24,NT=4,MODE=0>"),           # late_conv1 (two channel chunks per tile)
+    (64, 48, 64, 64, 2, "conv_ws<TH=8,TW=24,NT=4,MODE=2>"),            # nearest-x2 + conv, 64 couts
+    (8, 96, 64, 64, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),       # fewer than two tiles per persistent workgroup
     (64, 48, 256, 128, 0, "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=0>"),    # L4.conv1 (48x48: 8x24 tiles, 128 couts)
     (64, 48, 128, 64, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),     # dgrad of L2.conv1 (48x48, 64 couts)
     (64, 24, 128, 256, 0, "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=0>"),    # L3.conv1 (24x24)
@@ -84,11 +86,44 @@ def test_conv3x3_fwd_full_size(K, B, H, Cin, Cout, mode, variant):
     assert_close(nchw(y), ref + res, BF, f"conv fwd {variant}")
 
 
+def test_conv3x3_silu_input_full_size(K):
+    """late_conv2 at B=64 (SiLU applied while staging the input): stays on conv_mfma_kernel's 16x16 x 64-cout tile."""
+    B, H, Cin, Cout = 64, 96, 64, 64
+    x = q16(rnd(B, Cin, H, H, seed=1))
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    bias = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(q16(F.silu(x)), q16(w), bias, padding=1)
+    y = K.conv3x3(nhwc(x), K.pack_weight(w), Cout, bias=bias, act_silu_in=True)
+    assert K.last_variant() == "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=0>"
+    assert_close(nchw(y), ref, BF, "conv fwd silu-in 16x16 NT=4")
+
+
+def test_conv_ws_matches_conv_mfma_bitwise(K, monkeypatch):
+    """The wave-specialised kernel accumulates in the same k order as conv_mfma_kernel: bit-identical outputs, with the
+    whole epilogue (bias, time-embedding add, dropout, residual) and a strided (concat-slice) input and output."""
+    B, H, Cin, Cout = 64, 48, 128, 64
+    xb = rnd(B, H, H, 3 * Cin, seed=1).to(torch.bfloat16)
+    x = xb[..., Cin:2 * Cin]
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * Cin))
+    wp = K.pack_weight(w)
+    kw = dict(bias=rnd(Cout, seed=3), chan_add=rnd(B, Cout, seed=4), res=rnd(B, 2 * H, 2 * H, Cout, seed=5).to(torch.bfloat16),
+              drop_p=0.1, drop_seed=11, mode=2)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DM_CONV_WS", flag)
+        yb = torch.zeros(B, 2 * H, 2 * H, 2 * Cout, device=dev(), dtype=torch.bfloat16)
+        K.conv3x3(x, wp, Cout, out=yb[..., Cout:], **kw)
+        outs[flag] = (K.last_variant(), yb)
+    assert outs["1"][0] == "conv_ws<TH=8,TW=24,NT=4,MODE=2>" and outs["0"][0].startswith("conv_mfma<")
+    assert torch.equal(outs["1"][1], outs["0"][1])
+
+
 CONV_DGRAD = [
     # (B, H of dy, C of dy, C of dx, kind, variant)
     (64, 96, 128, 128, "pool2", "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=0>"),   # dgrad of L4.upsample.conv (2x2-pooled)
     (64, 48, 128, 128, "zi", "conv_mfma<TH=16,TW=16,S=1,NT=8,MODE=3>"),      # dgrad of a stride-2 conv -> 96x96
-    (64, 48, 64, 64, "zi", "conv_mfma<TH=16,TW=16,S=1,NT=4,MODE=3>"),        # dgrad of L1.downsample
+    (64, 48, 64, 64, "zi", "conv_ws<TH=8,TW=24,NT=4,MODE=3>"),               # dgrad of L1.downsample (wave-specialised)
+    (8, 48, 64, 64, "zi", "conv_mfma<TH=8,TW=24,S=1,NT=4,MODE=3>"),          # the same at a batch too small for it
     (64, 24, 128, 128, "zi", "conv_mfma<TH=8,TW=24,S=1,NT=8,MODE=3>"),       # dgrad of L2.downsample -> 48x48
 ]
 
