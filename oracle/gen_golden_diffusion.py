@@ -84,6 +84,28 @@ def loop_statements(fname, outer, first_target, last_test_attr):
     raise KeyError(f"{fname}: loop statements of {outer}")
 
 
+def with_block_statements(fname, outer, first_target, last_target):
+    """Source of the consecutive statements inside ``outer``'s ``with`` block from the assignment to ``first_target``
+    through the assignment to ``last_target``, dedented (verbatim lines, comments included)."""
+    src, tree = _tree(fname)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == outer)
+    for w in ast.walk(fn):
+        if not isinstance(w, ast.With):
+            continue
+        start = end = None
+        for i, st in enumerate(w.body):
+            if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name):
+                if start is None and st.targets[0].id == first_target:
+                    start = i
+                if start is not None and st.targets[0].id == last_target:
+                    end = i
+                    break
+        if start is not None and end is not None:
+            lines = src.splitlines()[w.body[start].lineno - 1: w.body[end].end_lineno]
+            return textwrap.dedent("\n".join(lines))
+    raise KeyError(f"{fname}: with-block statements of {outer}")
+
+
 def base_ns():
     cfg = types.SimpleNamespace(UNCOND_ID=10, USING_LOW_T_REWARDING=True, LOW_T_REWARDING_WARMUP_EPOCHS=20,
                                 LOW_T_REWARDING_WARMUP_WEIGHT=0.01)
@@ -174,6 +196,46 @@ def main():
         save(f"ref_reverse_T{nsteps}", z0=z0, labels=lab2, x0=x0, noises=noises, eta=torch.tensor(eta),
              guidance=torch.tensor(gs), **{f"snap_t{k}": v for k, v in snaps.items()})
     del T
+
+    # ---------------------------------------------------------------- monitoring images (visualization.py:40-69, 183-330)
+    # Image CONTENT of the monitoring functions: tensor_to_image, the collage's snapshots (run_reverse_process +
+    # tensor_to_image, :205-222) and the reconstruction panels (:287-314).  The matplotlib figure around them is not
+    # reproduced (matplotlib is absent); sample_noise() draws on a CUDA device by default, so the start noise is supplied.
+    nm = base_ns()
+    nm.update(LDM=False, IMAGE_NET=False, np=np, UNCOND_ID=10)
+    exec(top_level("visualization.py", "tensor_to_image"), nm)
+    exec(top_level("visualization.py", "_ddpm_step"), nm)
+    exec(top_level("visualization.py", "run_reverse_process"), nm)
+    mon = {}
+    gm = torch.Generator().manual_seed(21)
+    probe = torch.randn(2, 3, 6, 5, generator=gm) * 0.9
+    mon["t2i_in"] = probe
+    mon["t2i_out"] = nm["tensor_to_image"](probe)             # first of the batch, clamp((x+1)/2), HWC
+    mon["t2i_chw_out"] = nm["tensor_to_image"](probe[1])
+    zc = torch.randn(1, 3, 16, 16, generator=gm)
+    labc = torch.tensor([6])
+    caps = [9, 5, 2, 0]
+    _, snaps = nm["run_reverse_process"](StubNet(), sched, zc, labc, 4.0, 0.0, 12, predict, capture_timesteps=caps)
+    mon.update(collage_z=zc, collage_label=labc, collage_caps=np.array(caps), collage_guidance=np.array(4.0),
+               collage_steps=np.array(12))
+    for t in caps:
+        mon[f"collage_img_t{t}"] = nm["tensor_to_image"](snaps[t])
+    body = with_block_statements("visualization.py", "reconstruct_from_dataset_sample", "t0", "x0_hat")
+    xr = torch.clamp(torch.randn(1, 3, 16, 16, generator=gm) * 0.5, -1, 1)
+    for gs, tag in ((3.0, "cfg"), (0.0, "uncond")):
+        lab = torch.tensor([2])
+        nr = dict(nm)
+        nr.update(num_time_steps=500, t_start=9, scheduler=sched, device=torch.device("cpu"), x=xr.clone(),
+                  labels=(lab if gs != 0.0 else torch.full_like(lab, 10)),       # :284-285
+                  predict_eps_fn=predict, model=StubNet(), guidance_scale=gs, sampling_eta=0.0)
+        torch.manual_seed(515)
+        exec(body, nr)
+        mon.update({f"recon_{tag}_x": xr, f"recon_{tag}_xt": nr["x_t"], f"recon_{tag}_x0hat": nr["x0_hat"],
+                    f"recon_{tag}_img_orig": nm["tensor_to_image"](torch.clamp(xr, -1, 1)),
+                    f"recon_{tag}_img_xt": nm["tensor_to_image"](torch.clamp(nr["x_t"], -1, 1)),
+                    f"recon_{tag}_img_recon": nm["tensor_to_image"](torch.clamp(nr["x0_hat"], -1, 1)),
+                    f"recon_{tag}_t0": np.array(nr["t0"]), f"recon_{tag}_label": lab})
+    save("ref_monitoring", **mon)
 
     # ---------------------------------------------------------------- LR lambda (main_stl10.py:405-412)
     for total in (7900, 200):

@@ -175,3 +175,68 @@ def test_callback_contract_reverse_process_equals_reference_code():
     assert_close(x0, g["x0"], 2e-5, "x0")
     for t in (5, 2, 0):
         assert_close(snaps[t], g[f"snap_t{t}"], 2e-5, f"snapshot t={t}")
+
+
+# --------------------------------------------------------------------------- monitoring images
+def test_tensor_to_image_equals_reference_code():
+    """visualization.tensor_to_image against the reference's own function (visualization.py:40-69) on the same tensors:
+    bit-equal (clamp((x + 1) / 2, 0, 1), first of a batch, HWC)."""
+    from diffusion_model_amd import visualization as V
+    g = load_golden("ref_monitoring")
+    assert np.array_equal(V.tensor_to_image(g["t2i_in"]), g["t2i_out"].numpy())
+    assert np.array_equal(V.tensor_to_image(g["t2i_in"][1]), g["t2i_chw_out"].numpy())
+
+
+class _StubUNet(torch.nn.Module):
+    """oracle.stub_model behind the product UNET's internal interface (CFGSampler calls model._fwd)."""
+
+    def _fwd(self, z, t, ctx):
+        return stub_model(z, t, ctx), None
+
+    def forward(self, z, t, ctx):
+        return stub_model(z, t, ctx)
+
+
+def _png_tiles(path, n, side, scale):
+    """The n image tiles of a visualization.save_image_strip sheet, back at their own resolution, as uint8 HWC."""
+    from PIL import Image
+    a = np.asarray(Image.open(path).convert("RGB"))
+    w = side * scale
+    return [a[18:18 + w:scale, 4 + i * (w + 4): 4 + i * (w + 4) + w: scale] for i in range(n)]
+
+
+@pytest.mark.gpu
+def test_monitoring_images_equal_reference_code(tmp_path, monkeypatch):
+    """The IMAGE CONTENT of the monitoring PNGs -- generate_denoise_collage's panels and reconstruct_from_dataset_sample's
+    three panels, produced by the batched jobs on the fused sampler -- against what the reference's own code
+    (run_reverse_process + tensor_to_image; the statements of reconstruct_from_dataset_sample from t0 to x0_hat) computed
+    for the same start noise, stand-in model, labels and guidance, eta = 0 (the reference draws its noise on the CPU
+    generator).  One grey level of slack for the uint8 rounding of values that differ by fp32 summation order."""
+    from diffusion_model_amd import utils, visualization as V
+    dev = torch.device("cuda:0")
+    g = load_golden("ref_monitoring")
+    utils._load_clip_context_table()
+    sched = utils.DDPM_beta_t_cosine_scheduler(500)
+    model = _StubUNet()
+    out = str(tmp_path)
+
+    def u8(img):
+        return (img.numpy() * 255.0 + 0.5).astype(np.uint8).astype(np.int16)
+
+    # ---- collage
+    caps = [int(t) for t in g["collage_caps"]]
+    monkeypatch.setattr(V, "sample_noise", lambda *a, **k: g["collage_z"].clone())
+    V.generate_denoise_collage(model, sched, 1, 2, caps, dev, int(g["collage_steps"]), 0.0, None, out,
+                               labels=g["collage_label"].to(dev), guidance_scale=float(g["collage_guidance"]))
+    tiles = _png_tiles(tmp_path / "epoch_1" / "epoch_1_step_2_stl10_collage.png", len(caps), 16, 2)
+    for t, tile in zip(caps, tiles):
+        assert np.abs(tile.astype(np.int16) - u8(g[f"collage_img_t{t}"])).max() <= 1, f"collage panel t={t}"
+    # ---- reconstruction, guided and unconditional (guidance 0.0 swaps the label for the null one, :284-285)
+    for tag, gs in (("cfg", 3.0), ("uncond", 0.0)):
+        monkeypatch.setattr(V, "_noised", lambda scheduler, x, t0, _xt=g[f"recon_{tag}_xt"]: _xt.to(x.device))
+        ds = [(g[f"recon_{tag}_x"][0], int(g[f"recon_{tag}_label"]))]
+        t0 = int(g[f"recon_{tag}_t0"])
+        V.reconstruct_from_dataset_sample(model, sched, ds, 5, dev, 500, 0.0, None, out, t_start=t0, guidance_scale=gs)
+        tiles = _png_tiles(tmp_path / "epoch_5" / f"epoch_5_reconstruction_t{t0}.png", 3, 16, 2)
+        for name, tile in zip(("orig", "xt", "recon"), tiles):
+            assert np.abs(tile.astype(np.int16) - u8(g[f"recon_{tag}_img_{name}"])).max() <= 1, f"{tag} panel {name}"
