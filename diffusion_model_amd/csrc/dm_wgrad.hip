@@ -112,56 +112,81 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     const int vh0 = (MODE == WM_S2) ? 2 * h0 - 1 : h0 - 1;
     const int vw0 = (MODE == WM_S2) ? 2 * w0 - 1 : w0 - 1;
+    // Buffer loads: an out-of-range offset returns 0, so padding / overhang / ragged rows need no select on the
+    // loaded value.  (A `valid ? v : 0` right after the load made the compiler wait for the whole prefetch BEFORE the
+    // MFMA phase it was meant to overlap -- s_waitcnt vmcnt(0) ahead of the k-loop.)  GEMM mode: 2 GiB windows.
+    constexpr int OOB = 0x7ffffff0;
     if (do_x) { xmask = 0u; xb = b; }
-    if (do_x)
-#pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int idx = tid + i * 256;
-      const int piece = idx & 7;
-      const int pix = idx >> 3;
-      const int pr = pix / PW, pc = pix % PW;
-      bool valid = idx < X_PIECES;
-      long src;
-      const int ch = cit * 64 + piece * 8;
+    if (do_x) {
+      const bf16* xbase;
+      long xspan;   // elements addressable from xbase
+      long xrow0 = 0;
       if constexpr (MODE == WM_GEMM) {
-        const long m = m0 + pix;
-        valid = valid && (m < p.M) && (ch < p.Cin);
-        src = m * p.ldx + ch;
+        xrow0 = m0;
+        xbase = p.x + m0 * p.ldx;
+        xspan = (p.M - m0 - 1) * p.ldx + p.Cin;
       } else {
-        const int vh = vh0 + pr, vw = vw0 + pc;
-        int sh = vh, sw = vw;
-        if constexpr (MODE == WM_UP) {
-          valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
-          sh = vh >> 1; sw = vw >> 1;
+        xbase = p.x + (long)b * p.Hi * p.Wi * p.ldx;
+        xspan = ((long)p.Hi * p.Wi - 1) * p.ldx + p.Cin;
+      }
+      (void)xrow0;
+      const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)(xspan * 2 > 0x7fffffffL ? 0x7fffffffL : xspan * 2), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int idx = tid + i * 256;
+        const int piece = idx & 7;
+        const int pix = idx >> 3;
+        const int pr = pix / PW, pc = pix % PW;
+        bool valid = idx < X_PIECES;
+        int off;
+        const int ch = cit * 64 + piece * 8;
+        if constexpr (MODE == WM_GEMM) {
+          valid = valid && (m0 + pix < p.M) && (ch < p.Cin);
+          off = (pix * (int)p.ldx + ch) * 2;
         } else {
-          valid = valid && (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+          const int vh = vh0 + pr, vw = vw0 + pc;
+          int sh = vh, sw = vw;
+          if constexpr (MODE == WM_UP) {
+            valid = valid && (vh >= 0) && (vh < 2 * p.Hi) && (vw >= 0) && (vw < 2 * p.Wi);
+            sh = vh >> 1; sw = vw >> 1;
+          } else {
+            valid = valid && (vh >= 0) && (vh < p.Hi) && (vw >= 0) && (vw < p.Wi);
+          }
+          off = ((sh * p.Wi + sw) * (int)p.ldx + ch) * 2;
         }
-        src = (((long)b * p.Hi + sh) * p.Wi + sw) * p.ldx + ch;
+        px[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, valid ? off : OOB, 0, 0));
+        if constexpr (NORM) xmask |= (valid ? 1u : 0u) << i;
       }
-      const u32x4 v = *reinterpret_cast<const u32x4*>(p.x + (valid ? src : 0));  // offset 0 is readable
-      px[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
-      if constexpr (NORM) xmask |= (valid ? 1u : 0u) << i;
     }
-    if (do_d)
-#pragma unroll
-    for (int i = 0; i < NPD; ++i) {
-      const int idx = tid + i * 256;
-      const int piece = idx & 7;
-      const int q = idx >> 3;
-      const int ch = cot * 64 + piece * 8;
-      long src;
-      bool valid = ch < p.Cout;
+    if (do_d) {
+      const bf16* dbase;
+      long dspan;
       if constexpr (MODE == WM_GEMM) {
-        const long m = m0 + q;
-        valid = valid && (m < p.M);
-        src = m * p.lddy + ch;
+        dbase = p.dy + m0 * p.lddy;
+        dspan = (p.M - m0 - 1) * p.lddy + p.Cout;
       } else {
-        const int r = q / TW, c = q % TW;
-        valid = valid && (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile overhangs the image
-        src = (((long)b * p.Ho + (h0 + r)) * p.Wo + (w0 + c)) * p.lddy + ch;
+        dbase = p.dy + (long)b * p.Ho * p.Wo * p.lddy;
+        dspan = ((long)p.Ho * p.Wo - 1) * p.lddy + p.Cout;
       }
-      const u32x4 v = *reinterpret_cast<const u32x4*>(p.dy + (valid ? src : 0));
-      pd[i] = valid ? v : u32x4{0u, 0u, 0u, 0u};
+      const auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, (int)(dspan * 2 > 0x7fffffffL ? 0x7fffffffL : dspan * 2), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NPD; ++i) {
+        const int idx = tid + i * 256;
+        const int piece = idx & 7;
+        const int q = idx >> 3;
+        const int ch = cot * 64 + piece * 8;
+        int off;
+        bool valid = ch < p.Cout;
+        if constexpr (MODE == WM_GEMM) {
+          valid = valid && (m0 + q < p.M);
+          off = (q * (int)p.lddy + ch) * 2;
+        } else {
+          const int r = q / TW, c = q % TW;
+          valid = valid && (h0 + r < p.Ho) && (w0 + c < p.Wo);  // tile overhangs the image
+          off = (((h0 + r) * p.Wo + (w0 + c)) * (int)p.lddy + ch) * 2;
+        }
+        pd[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, valid ? off : OOB, 0, 0));
+      }
     }
   };
   auto store_tile = [&](u32x4(&px)[NPX], u32x4(&pd)[NPD], bool do_x, bool do_d) {
@@ -246,13 +271,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], ones, accb[t], 0, 0, 0);
       }
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
+      // the x fragment of tap + 1 is read while the four MFMAs of tap run (two alternating registers quads: with one,
+      // every tap paid the LDS latency between its read and its first MFMA)
+      auto xfrag = [&](int tap) {
         const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
         const int tapoff = (kh * XPITCH + kw) * XSTRIDE;
-        const bf16x8 bv = tr_pair(sX + xo[0] + tapoff, sX + xo[1] + tapoff);
+        return tr_pair(sX + xo[0] + tapoff, sX + xo[1] + tapoff);
+      };
+      bf16x8 bv = xfrag(0);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        bf16x8 bn = bv;
+        if (tap + 1 < TAPS) bn = xfrag(tap + 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bv, acc[tap][t], 0, 0, 0);
+        bv = bn;
       }
     }
   }
