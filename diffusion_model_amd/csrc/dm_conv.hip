@@ -500,9 +500,12 @@ struct ConvWalk {   // this workgroup's walk over its (tile, channel-chunk) unit
   }
 };
 
-template <int NT, int MODE>
+template <int NT, int MODE, int TW = 24>
 __global__ __launch_bounds__(512, 4) void conv_ws_kernel(const ConvParams p) {
-  constexpr int TH = 8, TW = 24, PH = TH + 2, PW = TW + 2, PITCH = PW, STRIDE = 144, MT = 3;
+  // patch pitch / pixel stride: conflict-free for the ds_read_b128 lane groups (brute-forced over the gfx950 group table:
+  // 24-wide tiles need pitch 32 at 160 B -- pitch 26 at 144 B, the first version, was up to 3-way conflicted on the
+  // pixel-operand reads; 16-wide tiles pitch 18 at 160 B)
+  constexpr int TH = 8, PH = TH + 2, PW = TW + 2, PITCH = (TW == 24) ? 32 : PW, STRIDE = 160, MT = TH * TW / 64;
   constexpr int A_BYTES = PH * PITCH * STRIDE;        // 37,440
   constexpr int KSPS = 2;                             // k-steps (of 32) per weight stage
   constexpr int B_STAGE = KSPS * NT * 1024;
@@ -689,11 +692,11 @@ __global__ __launch_bounds__(512, 4) void conv_ws_kernel(const ConvParams p) {
   }
 }
 
-template <int NT, int MODE>
+template <int NT, int MODE, int TW = 24>
 int launch_conv_ws(const ConvParams& p0, hipStream_t st) {
-  constexpr int LDS = 10 * 26 * 144 + 2 * 2 * NT * 1024;
+  constexpr int LDS = 10 * ((TW == 24) ? 32 : TW + 2) * 160 + 2 * 2 * NT * 1024;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  auto k = conv_ws_kernel<NT, MODE>;
+  auto k = conv_ws_kernel<NT, MODE, TW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -719,7 +722,7 @@ int launch_conv_ws(const ConvParams& p0, hipStream_t st) {
   if (gx > p.ntiles) gx = p.ntiles;
   const int rounds = (p.ntiles + gx - 1) / gx;
   gx = (p.ntiles + rounds - 1) / rounds;   // same number of rounds, evenly filled
-  static const DmVariantName vn("conv_ws<TH=8,TW=24,NT=%d,MODE=%d>", NT, MODE);
+  static const DmVariantName vn("conv_ws<TH=8,TW=%d,NT=%d,MODE=%d>", TW, NT, MODE);
   dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, dim3((unsigned)gx, (unsigned)gy), dim3(512), LDS, st, p);
   DM_LAUNCH_CHECK();
