@@ -89,10 +89,14 @@ __device__ __forceinline__ Stager<DT> make_stager(const bf16* A, long lda, const
   Stager<DT> s;
   constexpr uint32_t OOB = 0x7FFFFFFFu;  // beyond any descriptor's range, also after the block steps are added
   if constexpr (DT == 1) {
-    const bool second = wave >= 2;  // wave-uniform
+    // wave-uniform, and SAID so: with `wave` derived from threadIdx the descriptor is a per-lane value to the compiler,
+    // every buffer load becomes a waterfall loop (v_readfirstlane + s_cbranch_execnz), and the control flow makes the
+    // waitcnt pass drain ALL loads (vmcnt(0)) where the two-blocks-ahead prefetch needs a counted wait
+    const bool second = __builtin_amdgcn_readfirstlane(wave) >= 2;
     const bf16* base = (second ? B + tokbase * ldb : A + tokbase * lda) + hoff;
     const long ld = second ? ldb : lda;
-    s.ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((long)(n_tok - 1) * ld + hd) * 2), 0x00020000);
+    const int nrec = __builtin_amdgcn_readfirstlane((int)(((long)(n_tok - 1) * ld + hd) * 2));
+    s.ra = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
     s.rb = s.ra;
     const int row = (tid & 127) >> 1, pc = tid & 1;
     s.va = pc * 8 < hd ? (uint32_t)(row * ld * 2 + pc * 16) : OOB;
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
   if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(seed_eff, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
-    if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
+    stage_load<DT>(r_free, stg, kb + 2);   // unconditional: past the end the descriptor's range check returns zeros (no
+                                           // traffic), and a branch here would make the waitcnt pass drain the prefetch
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 st[4][2];  // c*s - m, straight out of the MFMA
@@ -315,9 +320,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
     __syncthreads();
   };
-  for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, r0, r1);
-    if (kb + 1 < nkb) block(kb + 1, r1, r0);
+  {  // block pairs, an odd last block peeled off: a mid-loop exit is one more path into the loop header on which the
+     // youngest prefetch is still in flight, and the waitcnt pass then drains it at the header on every trip
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+      block(kb, r0, r1);
+      block(kb + 1, r1, r0);
+    }
+    if (kb < nkb) block(kb, r0, r1);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -420,23 +430,25 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   const float keepf = DROP ? p.keep : 1.f;
   // Q / dO / LSE / delta blocks: two blocks ahead in registers, one ahead in the other LDS buffer.
   const Stager<DT> stg = make_stager<DT>(p.q, p.ldq, p.d_o, p.lddo, qbase, p.Nq, hoff, p.hd, tid, wave);
-  struct Regs { Stage<DT> st; float l, d; uint32_t rs; };
+  struct Regs { Stage<DT> st; float l, d; uint32_t rs; bool ok; };
   auto fetch = [&](int qb, Regs& r) {
     stage_load<DT>(r.st, stg, qb);
     if (wave == 0) {  // wave 0 carries the per-query scalars
       const int q = qb * 64 + tid;
       const bool ok = q < p.Nq;
       const long li_ = (long)bh * p.Nq + (ok ? q : 0);
-      const float lv = p.lse[li_] * LOG2E, dv = p.delta[li_];
-      r.l = ok ? -lv : -1e30f;  // out-of-range query: p = exp2(-huge) = 0
-      r.d = ok ? -dv * keepf : 0.f;
+      // RAW values only: any arithmetic on them here makes wave 0 wait for the loads (and, vmcnt being in order, for the
+      // block data ahead of them) before the block it should overlap -- and the other three waves wait for wave 0 at
+      // the barrier.  The scaling happens in put(), two blocks later.
+      r.l = p.lse[li_]; r.d = p.delta[li_]; r.ok = ok;
       if (DROP) r.rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q)) & M15;
     }
   };
   auto put = [&](int buf, const Regs& r) {
     stage_store<DT>(r.st, sQb[buf], sOb[buf], tid);
     if (wave == 0) {
-      sLb[buf][tid] = r.l; sDb[buf][tid] = r.d;
+      sLb[buf][tid] = r.ok ? -(r.l * LOG2E) : -1e30f;  // out-of-range query: p = exp2(-huge) = 0
+      sDb[buf][tid] = r.ok ? -r.d * keepf : 0.f;
       if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][ROFF + tid] = r.rs >> 16; }
     }
   };
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
   put(0, r0);
   __syncthreads();
   auto block = [&](int qb, Regs& r_free, const Regs& r_next) {
-    if (qb + 2 < nqb) fetch(qb + 2, r_free);
+    fetch(qb + 2, r_free);   // unconditional (clamped scalars, range-checked block data): see stage_load in the forward
     const char* sQ = sQb[qb & 1];
     const char* sO = sOb[qb & 1];
     const float* sL = sLb[qb & 1];
@@ -495,9 +507,14 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_kv_kernel(const
     if (qb + 1 < nqb) put((qb + 1) & 1, r_next);
     __syncthreads();
   };
-  for (int qb = 0; qb < nqb; qb += 2) {
-    block(qb, r0, r1);
-    if (qb + 1 < nqb) block(qb + 1, r1, r0);
+  {  // block pairs, an odd last block peeled off: a mid-loop exit is one more path into the loop header on which the
+     // youngest prefetch is still in flight, and the waitcnt pass then drains it at the header on every trip
+    int qb = 0;
+    for (; qb + 1 < nqb; qb += 2) {
+      block(qb, r0, r1);
+      block(qb + 1, r1, r0);
+    }
+    if (qb < nqb) block(qb, r0, r1);
   }
   const float ik = DROP ? p.inv_keep : 1.f;  // dropout rescale of P (dV) and of dS (dK) folded into the epilogue
   if (key_ok) {
@@ -558,7 +575,8 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
   if (DROP && wave == 0 && tid < 32) sCb[0][tid] = dm_attn_colword(seed_eff, (uint32_t)tid) & M15;
   __syncthreads();
   auto block = [&](int kb, Stage<DT>& r_free, const Stage<DT>& r_next) {
-    if (kb + 2 < nkb) stage_load<DT>(r_free, stg, kb + 2);
+    stage_load<DT>(r_free, stg, kb + 2);   // unconditional: past the end the descriptor's range check returns zeros (no
+                                           // traffic), and a branch here would make the waitcnt pass drain the prefetch
     const char* sK = sKb[kb & 1];
     const char* sV = sVb[kb & 1];
     f32x4 ds[4][2];
@@ -608,9 +626,14 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
     }
     __syncthreads();
   };
-  for (int kb = 0; kb < nkb; kb += 2) {
-    block(kb, r0, r1);
-    if (kb + 1 < nkb) block(kb + 1, r1, r0);
+  {  // block pairs, an odd last block peeled off: a mid-loop exit is one more path into the loop header on which the
+     // youngest prefetch is still in flight, and the waitcnt pass then drains it at the header on every trip
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+      block(kb, r0, r1);
+      block(kb + 1, r1, r0);
+    }
+    if (kb < nkb) block(kb, r0, r1);
   }
   const float osc = p.scale * (DROP ? p.inv_keep : 1.f);
 #pragma unroll
