@@ -762,16 +762,22 @@ __global__ __launch_bounds__(256, (WIDE && MT == 1 && NKS <= 4) ? 3 : 2) void ge
   const int nks_real = ((p.Cin + 63) >> 6) * 2;
   const int row_l = lane & 15, kq = (lane >> 4) * 8;
 
+  // X fragments come through a buffer descriptor over the tile's rows: rows past M and channels past Cin read as 0
+  // by the hardware range check (an out-of-range offset), with no select on the loaded value -- a `valid ? v : 0` makes
+  // the compiler wait for the prefetch where it is issued, not where it is used.
   auto load_x = [&](int tile, bf16x8(&xa)[MT][NKS]) {
+    const long row0 = (long)__builtin_amdgcn_readfirstlane(tile) * (MT * 16);
+    long rows = p.M - row0;
+    rows = rows < 0 ? 0 : (rows > MT * 16 ? MT * 16 : rows);
+    const int nrec = rows > 0 ? (int)(((rows - 1) * p.ldx + p.Cin) * 2) : 0;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (rows > 0 ? row0 : 0) * p.ldx), 0, nrec, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const long m = ((long)tile * MT + mt) * 16 + row_l;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const int ch = ks * 32 + kq;
-        const bool valid = (m < p.M) && (ch < p.Cin);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x + (valid ? m * p.ldx + ch : 0));
-        xa[mt][ks] = valid ? v : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+        const int off = (ch < p.Cin) ? ((mt * 16 + row_l) * (int)p.ldx + ch) * 2 : 0x7ffffff0;
+        xa[mt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
       }
     }
   };
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(256, (WIDE && MT == 1 && NKS <= 4) ? 3 : 2) void ge
 
   auto work = [&](int t, bf16x8(&xa)[MT][NKS], bf16x8(&xn)[MT][NKS]) {
     asm volatile("" ::: "memory");  // keep the epilogue's per-column loads (bias) inside the tile loop: hoisted, they cost 32+ VGPRs
-    if (t + nwaves < ntiles) load_x(t + nwaves, xn);
+    load_x(t + nwaves, xn);   // unconditional: past the last tile the descriptor is empty (zeros, no traffic)
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -830,10 +836,11 @@ __global__ __launch_bounds__(256, (WIDE && MT == 1 && NKS <= 4) ? 3 : 2) void ge
     }
     conv_epilogue<MT, NT, 16, MODE_GEMM, WIDE>(p, acc, nb, 0, lane, 0, 0, 0, (long)t * MT * 16);
   };
-  for (; tile < ntiles; tile += 2 * nwaves) {
+  for (; tile + nwaves < ntiles; tile += 2 * nwaves) {   // tile pairs, an odd last tile peeled off
     work(tile, xa0, xa1);
-    if (tile + nwaves < ntiles) work(tile + nwaves, xa1, xa0);
+    work(tile + nwaves, xa1, xa0);
   }
+  if (tile < ntiles) work(tile, xa0, xa1);
 }
 
 template <int MT, int NT, int NKS, bool WIDE>
