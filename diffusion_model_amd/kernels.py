@@ -313,6 +313,7 @@ class on_aux:
         self.dev = torch.device(device)
 
     def __enter__(self):
+        flush_side()   # weight gradients queued so far fork from the CURRENT stream, not from the auxiliary one
         aux, ev = aux_stream(self.dev)
         ev.record()
         aux.wait_event(ev)
@@ -322,7 +323,19 @@ class on_aux:
         return aux
 
     def __exit__(self, *exc):
+        flush_side()   # weight gradients queued inside fork from the auxiliary stream (their operands are produced there)
         return self.ctx.__exit__(*exc)
+
+
+def hold_for_aux(device, *tensors) -> None:
+    """Tensors of the current stream that kernels on the auxiliary stream read, and that the caller may free before
+    ``join_aux``: keep the caching allocator from recycling them early."""
+    aux, _ = aux_stream(device)
+    for t in tensors:
+        if CAPTURE_KEEPALIVE is not None:
+            CAPTURE_KEEPALIVE.append((t,))
+        else:
+            t.record_stream(aux)
 
 
 def join_aux(device) -> None:

@@ -205,6 +205,7 @@ class _Fn(torch.autograd.Function):
     def backward(ctx, dout):
         g = Grads()
         dins = ctx.mod._run_bwd(dout.contiguous(), ctx.saved, g, ctx.need_in)
+        K.join_aux(dout.device)   # overlapped attention backward branches (UnetLayer._bwd)
         K.join_side(dout.device)  # weight gradients were enqueued on the side stream
         dins = list(dins) + [None] * (ctx.n_in - len(dins))
         pg = []
@@ -559,6 +560,7 @@ ELIDE_DEAD_ATTENTION = [os.environ.get("DM_ELIDE_DEAD_ATTENTION", "0") == "1"]
 # the attention call that yields the log-sum-exp -- is enqueued on an auxiliary HIP stream, where its VALU-bound
 # kernels run beside the MFMA-bound convolutions of the main chain.  The main stream joins it at the end of the forward.
 OVERLAP_DEAD_ATTENTION = [os.environ.get("DM_OVERLAP_DEAD_ATTENTION", "1") != "0"]
+KEEP_DEAD_DX = [False]   # tests: keep the (zero) input gradient of the overlapped backward branch in UnetLayer._dead_dx
 
 
 class UnetLayer(HipModule):
@@ -657,6 +659,19 @@ class UnetLayer(HipModule):
             if hasattr(self, "attention"):  # zero gradients, exactly: leave the accumulators untouched
                 g.of(self.attention.linear_qkv.weight), g.of(self.attention.linear_out.weight)
             dr = dxo  # d(xo)/d(r) is the residual branch alone
+        elif s_a is not None and s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1:
+            # One context token: d(cross_attention)/d(its query input) is exactly 0 (dq = 0 out of a softmax over one
+            # key), so the gradient that comes back through attention(r) is an exact zero and dr = dxo.  Everything
+            # still runs -- cross-attention backward (to_out / to_v / to_q / to_k gradients) and the whole self-attention
+            # backward -- but on the auxiliary stream, beside the ResBlock backward that no longer waits for it; the
+            # zero it returns is not added (tests/test_gpu_modules.py checks that it IS zero, bit for bit).
+            with K.on_aux(dxo.device):
+                K.hold_for_aux(dxo.device, dxo)
+                dxa, _ = self.cross_attention._bwd(dxo, s_c, g)
+                self._dead_dx = self.attention._bwd(dxa, s_a, g) if KEEP_DEAD_DX[0] else None
+                if not KEEP_DEAD_DX[0]:
+                    self.attention._bwd(dxa, s_a, g)
+            dr = dxo
         elif s_a is not None and s_c is not None:
             dxa, _ = self.cross_attention._bwd(dxo, s_c, g)
             dr = self.attention._bwd(dxa, s_a, g, add=dxo)
@@ -818,6 +833,7 @@ class UNET(HipModule):
         dh1 = K.silu_bwd(dsh1, h1)
         K.wgrad_side(e16, dh1, g.of(l0.weight), g.of(l0.bias), taps=1)
         hook("tail")
+        K.join_aux(da_dev)   # the overlapped attention backward branches are part of this backward (saved tensors die with it)
         if join:  # join=False: the caller joins before it consumes the gradients (Trainer: before the optimizer step),
             K.join_side(da_dev)  # so the tail of the weight-gradient stream overlaps the next micro-batch's forward
         return dx

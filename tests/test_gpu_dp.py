@@ -33,11 +33,21 @@ def _make(seed):
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException:   # report instead of leaving the peer (and the parent) waiting
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise
+
+
+def _worker_body(rank, world, port, q):
+    import datetime
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
         from diffusion_model_amd import kernels as K
         from diffusion_model_amd.trainer import Trainer
@@ -69,11 +79,22 @@ def test_data_parallel_two_ranks_match_gradient_accumulation():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:          # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r["rank"])
+    try:
+        res = [q.get(timeout=100) for _ in procs]
+    except Exception:
+        for p in procs:
+            p.kill()
+        raise AssertionError("a data-parallel rank did not report within 100 s (exit codes %s)" % [p.exitcode for p in procs])
+    for r in res:
+        assert "error" not in r, r["error"]
+    res = sorted(res, key=lambda r: r["rank"])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -210,3 +210,47 @@ def test_state_dict_is_reference_compatible():
     got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert list(got) == list(want) and got == want
     assert "time_embeddings.embeddings" not in got  # non-persistent buffer (reference unet.py:54)
+
+
+def test_overlapped_attention_backward_is_exact():
+    """One context token: UnetLayer._bwd runs the cross-attention and self-attention backward on the auxiliary stream and
+    does not add what comes back through attention(r) -- it must be an exact zero, and input / parameter gradients must
+    equal the single-stream order's."""
+    from diffusion_model_amd import unet as U
+    torch.manual_seed(3)
+    layer = U.UnetLayer(False, True, 8, 0.1, 64, 64, 256, num_heads=8, use_cross_attention=True, context_dim=512).to(dev())
+    layer.train()
+    B, H = 4, 24
+    x = torch.randn(B, H, H, 64, device=dev()).to(torch.bfloat16)
+    temb = torch.randn(B, 256, device=dev()).to(torch.bfloat16)
+    ctx = torch.randn(B, 1, 512, device=dev()).to(torch.bfloat16)
+    dy = torch.randn(B, H // 2, H // 2, 64, device=dev()).to(torch.bfloat16)
+    dsk = torch.randn(B, H, H, 64, device=dev()).to(torch.bfloat16)
+    outs = {}
+    for flag in (True, False):
+        U.OVERLAP_DEAD_ATTENTION[0] = flag
+        U.KEEP_DEAD_DX[0] = flag
+        try:
+            U.reseed_dropout(77, 0, 0)
+            y, xo, saved = layer._fwd(x, temb, ctx)
+            g = U.Grads()
+            dx, dts = layer._bwd(dy, dsk, saved, g)
+            K_ = U.K
+            K_.join_aux(dev()); K_.join_side(dev())
+            torch.cuda.synchronize()
+            outs[flag] = (dx.float().clone(), dts.float().clone() if torch.is_tensor(dts) else None,
+                          {n: g.peek(p).clone() for n, p in layer.named_parameters() if g.peek(p) is not None})
+            if flag:
+                dead = layer._dead_dx
+                assert dead is not None and float(dead.float().abs().max()) == 0.0, "the skipped add is not an exact zero"
+        finally:
+            U.OVERLAP_DEAD_ATTENTION[0] = True
+            U.KEEP_DEAD_DX[0] = False
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0]), "dx differs between the overlapped and the single-stream backward"
+    for n in b[2]:
+        ref = b[2][n]
+        err = float((a[2][n] - ref).abs().max())
+        assert err <= 1e-5 * max(1.0, float(ref.abs().max())), (n, err)   # (GroupNorm partial merges use fp32 atomics)
+    for n in ("attention.linear_qkv.weight", "attention.linear_out.weight", "cross_attention.to_q.weight", "cross_attention.to_k.weight"):
+        assert float(a[2][n].abs().max()) == 0.0, f"{n}: dead parameter with a non-zero gradient"
