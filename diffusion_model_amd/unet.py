@@ -165,6 +165,9 @@ class Grads:
     def __init__(self, views: Optional[Dict[int, torch.Tensor]] = None):
         self.views = views
         self.bufs: Dict[int, torch.Tensor] = {}
+        # gradient wrt the cross-attention context (fp32 [B, L, Dc]); None = not asked for.  Every CrossAttention of the
+        # network adds its share (UNET._bwd with need_dctx=True)
+        self.dctx: Optional[torch.Tensor] = None
 
     def of(self, p: Optional[torch.Tensor]):
         if p is None:
@@ -461,6 +464,8 @@ class CrossAttention(HipModule):
             dv = K.attn_onekey_bwd(vc, o, d_o, self.num_heads, drop_p=p, drop_seed=seed)
             K.wgrad_side(ctx, dv, g.of(self.to_v.weight), None, taps=1)
             g.of(self.to_q.weight), g.of(self.to_k.weight)  # (allocate the zero gradients for autograd callers)
+            if g.dctx is not None:   # dk = 0: the context gradient comes through to_v alone
+                self._add_dctx(g, None, dv)
             return add, None
         dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
         K.wgrad_side(tok, dq, g.of(self.to_q.weight), None, taps=1)
@@ -471,7 +476,19 @@ class CrossAttention(HipModule):
         if need_dctx:
             dctx = K.gemm(dk, PW.of(self.to_k).bwd, self.context_dim)
             dctx = K.gemm(dv, PW.of(self.to_v).bwd, self.context_dim, res=dctx)
+        if g.dctx is not None:
+            self._add_dctx(g, dk, dv)
         return dx.view(dy.shape), dctx
+
+    def _add_dctx(self, g: Grads, dk, dv):
+        """g.dctx += dk . Wk + dv . Wv (reference unet.py:200-201 differentiated; fp32 accumulation across layers)."""
+        B, L, _ = dv.shape
+        for d, lin in ((dk, self.to_k), (dv, self.to_v)):
+            if d is None:
+                continue
+            part = torch.empty((B, L, self.context_dim), dtype=torch.float32, device=dv.device)
+            K.gemm(d, PW.of(lin).bwd, self.context_dim, out_f32=part)
+            K.batchsum(part.view(1, -1), g.dctx.view(-1))
 
     def forward(self, x, context):
         return self._apply_fn(x, context)
@@ -659,7 +676,8 @@ class UnetLayer(HipModule):
             if hasattr(self, "attention"):  # zero gradients, exactly: leave the accumulators untouched
                 g.of(self.attention.linear_qkv.weight), g.of(self.attention.linear_out.weight)
             dr = dxo  # d(xo)/d(r) is the residual branch alone
-        elif s_a is not None and s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1:
+        elif (s_a is not None and s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1
+              and g.dctx is None):   # (a context gradient is accumulated across layers: keep that on one stream)
             # One context token: d(cross_attention)/d(its query input) is exactly 0 (dq = 0 out of a softmax over one
             # key), so the gradient that comes back through attention(r) is an exact zero and dr = dxo.  Everything
             # still runs -- cross-attention backward (to_out / to_v / to_q / to_k gradients) and the whole self-attention
@@ -772,8 +790,12 @@ class UNET(HipModule):
         return y, (x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2)
 
     # ------------------------------------------------------------------ hand-scheduled backward
-    def _bwd(self, dout, saved, g: Grads, need_dx=False, join=True):
+    def _bwd(self, dout, saved, g: Grads, need_dx=False, join=True, need_dctx=False):
+        """Returns dx (NCHW fp32 or None); with need_dctx the gradient wrt the context is left in g.dctx
+        (fp32 [B, L, Dc])."""
         x0, e16, h1, temb, ctx, saved_layers, cats, a1, a2 = saved
+        if need_dctx and ctx is not None:
+            g.dctx = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.device)
         L, half = self.num_layers, self.num_layers // 2
         cat = cats[L - 1]
         B, Hc, Wc, Cc = cat.shape
@@ -849,7 +871,8 @@ class UNET(HipModule):
             context = None  # legacy label tensor: ignored, as in the reference (main.py:177)
         if not torch.is_tensor(t):
             t = torch.as_tensor(t, dtype=torch.long)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or (torch.is_tensor(context) and context.requires_grad)
+                                        or any(p.requires_grad for p in self.parameters())):
             return _UNetFn.apply(self, x, t, context, *list(self.parameters()))
         y, _ = self._fwd(x, t, context)
         return y
@@ -869,14 +892,19 @@ class _UNetFn(torch.autograd.Function):
         y, saved = mod._fwd(x, t, context)
         ctx.mod, ctx.saved, ctx.params = mod, saved, params
         ctx.need_dx = x.requires_grad
+        ctx.need_dctx = torch.is_tensor(context) and torch.is_floating_point(context) and context.requires_grad
+        ctx.ctx_shape = tuple(context.shape) if torch.is_tensor(context) else None
         return y
 
     @staticmethod
     def backward(ctx, dout):
         g = Grads()
-        dx = ctx.mod._bwd(dout.contiguous(), ctx.saved, g, need_dx=ctx.need_dx)
+        dx = ctx.mod._bwd(dout.contiguous(), ctx.saved, g, need_dx=ctx.need_dx, need_dctx=ctx.need_dctx)
         pg = []
         for p in ctx.params:
             t = g.peek(p)
             pg.append(t if p.requires_grad else None)
-        return (None, dx, None, None, *pg)
+        dctx = None
+        if ctx.need_dctx:   # zeros when the network has no cross-attention (the context is then unused)
+            dctx = (g.dctx if g.dctx is not None else torch.zeros(ctx.ctx_shape, device=dout.device)).view(ctx.ctx_shape)
+        return (None, dx, None, dctx, *pg)

@@ -254,3 +254,56 @@ def test_overlapped_attention_backward_is_exact():
         assert err <= 1e-5 * max(1.0, float(ref.abs().max())), (n, err)   # (GroupNorm partial merges use fp32 atomics)
     for n in ("attention.linear_qkv.weight", "attention.linear_out.weight", "cross_attention.to_q.weight", "cross_attention.to_k.weight"):
         assert float(a[2][n].abs().max()) == 0.0, f"{n}: dead parameter with a non-zero gradient"
+
+
+@pytest.mark.parametrize("L", [0, 1, 5])
+def test_unet_context_gradient_vs_oracle(L):
+    """d(loss)/d(context) through all four cross-attention layers (reference unet.py:197-201 differentiated by autograd
+    there): one token as [B, 512] (L=0) or [B, 1, 512] -- the gradient arrives through to_v alone, dk being exactly zero --
+    and five tokens (general attention backward, dk . Wk + dv . Wv).  Checker: the oracle's fp32 autograd; bound = the
+    north-star's 2e-2 or 1.5x the oracle's own bf16-storage noise floor on the same inputs."""
+    from diffusion_model_amd.unet import UNET
+    torch.manual_seed(0)
+    m = UNET(**STL)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        m.output_conv.weight.copy_(torch.randn(m.output_conv.weight.shape, generator=gen) * 0.05)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    spec = oref.UNetSpec(**STL)
+    m = m.to(dev()).eval()
+    x = torch.randn(2, 3, 32, 32, generator=gen)
+    t = torch.tensor([17, 402])
+    G = torch.randn(2, 3, 32, 32, generator=gen)
+    shape = (2, 512) if L == 0 else (2, L, 512)
+    ctx = torch.nn.functional.normalize(torch.randn(shape, generator=gen), dim=-1)
+
+    def oracle_grad(emulate):
+        c = ctx.clone().requires_grad_()
+        oref.EMULATE_BF16 = emulate
+        try:
+            y = oref.unet_forward(sd, spec, x, t, c)
+            (gc,) = torch.autograd.grad((y * G).sum(), [c])
+        finally:
+            oref.EMULATE_BF16 = False
+        return y.detach(), gc
+
+    y_ref, g_ref = oracle_grad(False)
+    _, g_emu = oracle_grad(True)
+    floor = rel_l2(g_emu, g_ref)
+    cd = ctx.to(dev()).requires_grad_()
+    y = m(x.to(dev()), t, cd)
+    assert_close(y, y_ref, TOL, "y")
+    (y * G.to(dev())).sum().backward()
+    assert cd.grad is not None and tuple(cd.grad.shape) == shape and cd.grad.dtype == torch.float32
+    err = rel_l2(cd.grad, g_ref)
+    print(f"[L={L}] context gradient rel-L2 {err:.3e} (oracle bf16 floor {floor:.3e})")
+    assert err <= max(TOL, 1.5 * floor)
+    # parameter gradients are unchanged by asking for the context gradient
+    m2_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    y2 = m(x.to(dev()), t, ctx.to(dev()))
+    (y2 * G.to(dev())).sum().backward()
+    for n, p in m.named_parameters():
+        ref = p.grad
+        assert float((m2_grads[n] - ref).abs().max()) <= 1e-4 * max(1e-6, float(ref.abs().max())), n
