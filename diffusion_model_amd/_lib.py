@@ -85,6 +85,11 @@ _SIGS = {
     "dm_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "dm_add_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "dm_silu_bwd_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "dm_film_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_float, c_ulonglong,
+                            c_void_p]),
+    "dm_film_bwd_chunks": (c_int, [c_int]),
+    "dm_film_bwd": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int,
+                            c_int, c_void_p]),
     "dm_colsum_bf16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dm_batchsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dm_batchsum2_cast_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -100,6 +100,72 @@ __global__ void silu_bwd_kernel(const bf16* __restrict__ dy, long lddy, const bf
   }
 }
 
+// FiLM forward (reference unet.py:32-42 followed by the Dropout of unet.py:105): out[b][p][c] =
+// dropout(gamma[b][c] * h[b][p][c] + beta[b][c]); gb holds one fp32 row [gamma | beta] of 2C values per sample.
+// The dropout word of element (pixel, channel) is the one dm_conv3x3's epilogue and dm_gn_silu_bwd draw.
+__global__ void film_fwd_kernel(const bf16* __restrict__ h, long ldh, const float* __restrict__ gb,
+                                bf16* __restrict__ o, long ldo, long P, int HW, int C, uint32_t seed, uint32_t thresh,
+                                float scale, const uint32_t* __restrict__ ctr) {
+  const int vpp = C >> 3;
+  const long total = P * vpp;
+  const uint32_t seed_eff = dm_eff_seed(seed, ctr);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpp) * 8;
+    const long p = i / vpp;
+    const float* row = gb + (p / HW) * 2 * C;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + p * ldh + cv);
+    const uint32_t rs = thresh ? dm_drop_row(seed_eff, (uint32_t)p) : 0u;
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = row[cv + j] * (float)v[j] + row[C + cv + j];
+      if (thresh) f = dm_keep16(dm_drop_bits(rs, ((uint32_t)(cv + j)) >> 1), (uint32_t)j, thresh) ? f * scale : 0.f;
+      r[j] = (bf16)f;
+    }
+    *reinterpret_cast<bf16x8*>(o + p * ldo + cv) = r;
+  }
+}
+
+// FiLM backward: dh0 = gamma * dh, part[chunk][b][c] = sum over the chunk's pixels of dh * h0 (dgamma partials, summed
+// by the caller in chunk order: no atomics).  grid (nchunk, B).
+__global__ __launch_bounds__(256) void film_bwd_kernel(const bf16* __restrict__ dh, long lddh, const bf16* __restrict__ h0,
+                                                        long ldh, const float* __restrict__ gb, bf16* __restrict__ dh0,
+                                                        long ldo, float* __restrict__ part, int HW, int C) {
+  __shared__ float red[256 * 8];
+  const int chunk = blockIdx.x, nchunk = gridDim.x, b = blockIdx.y, B = gridDim.y, tid = threadIdx.x;
+  const int tpp = C >> 3, ppi = 256 / tpp;
+  const int c0 = (tid % tpp) * 8, prow = tid / tpp;
+  const int per = (HW + nchunk - 1) / nchunk;
+  const int p_end = min(HW, (chunk + 1) * per);
+  float s[8], ga[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (tid < tpp * ppi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ga[j] = gb[(long)b * 2 * C + c0 + j];
+    for (int r = chunk * per + prow; r < p_end; r += ppi) {
+      const long gp = (long)b * HW + r;
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(dh + gp * lddh + c0);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(h0 + gp * ldh + c0);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s[j] += (float)d[j] * (float)v[j];
+        o[j] = (bf16)(ga[j] * (float)d[j]);
+      }
+      *reinterpret_cast<bf16x8*>(dh0 + gp * ldo + c0) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int pr = 0; pr < ppi; ++pr) a += red[(pr * tpp + (c >> 3)) * 8 + (c & 7)];
+    part[((long)chunk * B + b) * C + c] = a;
+  }
+}
+
 // out[b][c] (fp32) = sum_p x[b][p][c]   (bias / chan_add gradients); grid (C/8 vec groups..., B)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ldx, float* __restrict__ out,
                                                       int rows, int C, int accumulate) {
@@ -403,6 +469,30 @@ extern "C" int dm_silu_bwd_bf16(const void* dy, long lddy, const void* x, long l
   DM_REQUIRE(dy && x && dx && C % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0);
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(P * (C >> 3))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                      (const bf16*)dy, lddy, (const bf16*)x, ldx, (bf16*)dx, lddx, P, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_film_fwd(const void* h, long ldh, const float* gamma_beta, void* out, long ldo, int B, int HW, int C,
+                          float drop_p, unsigned long long drop_seed, dm_stream_t stream) {
+  DM_REQUIRE(h && gamma_beta && out && B > 0 && HW > 0 && C % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0);
+  DM_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
+  const long P = (long)B * HW;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(ew_grid(P * (C >> 3))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     (const bf16*)h, ldh, gamma_beta, (bf16*)out, ldo, P, HW, C, dm_seed32(drop_seed), dm_thresh16(drop_p),
+                     dm_inv_keep(drop_p), drop_p > 0.f ? dm_dropout_counter() : nullptr);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_film_bwd_chunks(int HW) { return HW >= 4096 ? 16 : HW >= 256 ? 4 : 1; }
+
+extern "C" int dm_film_bwd(const void* dh, long lddh, const void* h0, long ldh, const float* gamma_beta, void* dh0,
+                          long ldo, float* dgamma_partials, int B, int HW, int C, dm_stream_t stream) {
+  DM_REQUIRE(dh && h0 && gamma_beta && dh0 && dgamma_partials && B > 0 && HW > 0);
+  DM_REQUIRE(C % 8 == 0 && C / 8 <= 256 && lddh % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0);
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(dm_film_bwd_chunks(HW), B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)dh, lddh, (const bf16*)h0, ldh, gamma_beta, (bf16*)dh0, ldo, dgamma_partials, HW, C);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

@@ -542,6 +542,35 @@ def silu_bwd(dy, x, out=None):
     return out
 
 
+def film_fwd(h, gamma_beta, drop_p=0.0, drop_seed=0):
+    """dropout(gamma * h + beta) for NHWC bf16 h [B, H, W, C] and fp32 rows gamma_beta [B, 2C] (unet.py:32-42,105)."""
+    B, Cc = h.shape[0], h.shape[-1]
+    HW = h.numel() // Cc // B
+    out = torch.empty(h.shape, dtype=BF16, device=h.device)
+    gb = _f32(gamma_beta, "gamma_beta")
+    assert gb.shape == (B, 2 * Cc) and gb.is_contiguous()
+    check(_lib.lib().dm_film_fwd(_p(h), _act(h, "h"), _p(gb), _p(out), _act(out, "out"), B, HW, Cc, float(drop_p),
+                                 int(drop_seed), _stream()), "dm_film_fwd")
+    return out
+
+
+def film_bwd(dh, h0, gamma_beta):
+    """Returns (dh0 = gamma * dh, dgamma [B, C] fp32 = sum over pixels of dh * h0)."""
+    B, Cc = h0.shape[0], h0.shape[-1]
+    HW = h0.numel() // Cc // B
+    dh0 = torch.empty(h0.shape, dtype=BF16, device=h0.device)
+    nch = _lib.lib().dm_film_bwd_chunks(HW)
+    part = torch.empty((nch, B * Cc), dtype=torch.float32, device=h0.device)
+    gb = _f32(gamma_beta, "gamma_beta")
+    check(_lib.lib().dm_film_bwd(_p(dh), _act(dh, "dh"), _p(h0), _act(h0, "h0"), _p(gb), _p(dh0), _act(dh0, "dh0"),
+                                 _p(part), B, HW, Cc, _stream()), "dm_film_bwd")
+    if nch == 1:
+        return dh0, part.view(B, Cc)
+    dgamma = torch.zeros((B, Cc), dtype=torch.float32, device=h0.device)
+    batchsum(part, dgamma.view(-1))   # chunk partials in fixed order
+    return dh0, dgamma
+
+
 def colsum(x, out, nbatch, accumulate=False):
     """out[b][c] (+)= sum over the batch's rows of x (x: [nbatch*rows, C] view)."""
     Cc = x.shape[-1]

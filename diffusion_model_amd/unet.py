@@ -259,14 +259,56 @@ class SinusoidalEmbeddings(nn.Module):
 FOLD_GROUPNORM = [os.environ.get("DM_FOLD_GROUPNORM", "0") == "1"]
 
 
+class FiLMLayer(HipModule):
+    """Reference unet.py:9-42: features * gamma + beta with [gamma | beta] = Linear(SiLU(conditioning))."""
+
+    def __init__(self, conditioning_dim: int, feature_dim: int):
+        super().__init__()
+        self.film_mlp = nn.Sequential(nn.SiLU(), nn.Linear(conditioning_dim, feature_dim * 2))
+        self.feature_dim = feature_dim
+
+    # cond: bf16 [B, conditioning_dim] (pre-SiLU); h0: NHWC bf16
+    def _fwd(self, h0, cond, drop_p=0.0, drop_seed=0):
+        lin = self.film_mlp[1]
+        gb = torch.empty((h0.shape[0], 2 * self.feature_dim), dtype=torch.float32, device=h0.device)
+        K.gemm(cond, PW.of(lin).fwd, 2 * self.feature_dim, bias=_b(lin), act_silu_in=True, out_f32=gb)
+        return K.film_fwd(h0, gb, drop_p, drop_seed), (h0, cond, gb)
+
+    def _bwd(self, dh, dbeta, saved, g: Grads):
+        """dh: gradient wrt gamma*h0+beta (dropout mask already applied); dbeta: its per-(sample, channel) sums, fp32
+        [B, C] (None: computed here).  Returns (dh0, gradient wrt silu(cond) as fp32 [B, conditioning_dim])."""
+        h0, cond, gb = saved
+        lin = self.film_mlp[1]
+        B, Cf = h0.shape[0], self.feature_dim
+        if dbeta is None:
+            dbeta = torch.empty((B, Cf), dtype=torch.float32, device=h0.device)
+            K.colsum(dh.view(-1, Cf), dbeta, B)
+        dh0, dgamma = K.film_bwd(dh, h0, gb)
+        dgb = torch.cat([dgamma, dbeta], dim=1)
+        dgb16 = K.batchsum2_cast(dgb, g.of(lin.bias))
+        K.wgrad_side(cond, dgb16, g.of(lin.weight), None, taps=1, act_silu_in=True)
+        dcond = torch.empty((B, cond.shape[-1]), dtype=torch.float32, device=h0.device)
+        K.gemm(dgb16, PW.of(lin).bwd, cond.shape[-1], out_f32=dcond)
+        return dh0, dcond
+
+    def forward(self, features, conditioning):
+        return self._apply_fn(features, conditioning)
+
+    def _run_fwd(self, features, conditioning):
+        y, saved = self._fwd(_nhwc_in(features), K.to_bf16(conditioning.detach().float().contiguous()))
+        return K.nhwc_to_nchw(y), saved
+
+    def _run_bwd(self, dout, saved, g, need):
+        dh0, dcond = self._bwd(_nhwc_in(dout), None, saved, g)
+        return K.nhwc_to_nchw(dh0), K.to_f32(K.silu_bwd(K.to_bf16(dcond), saved[1]))
+
+
 class ResBlock(HipModule):
     """Reference unet.py:70-108."""
 
     def __init__(self, in_channels: int, out_channels: int, time_emb_dim: int, num_groups: int,
                  dropout_prob: float, use_film: bool = False):
         super().__init__()
-        if use_film:
-            raise NotImplementedError("use_film=True is never used by the reference's entry points")
         self.relu = nn.SiLU()
         self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
         self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
@@ -275,11 +317,16 @@ class ResBlock(HipModule):
         self.norm2 = nn.GroupNorm(num_groups, out_channels)
         self.skip = nn.Conv2d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
         self.use_film = use_film
-        self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, out_channels))
+        if use_film:   # unet.py:82-84
+            self.film_layer = FiLMLayer(time_emb_dim, out_channels)
+        else:          # unet.py:85-90
+            self.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_emb_dim, out_channels))
         self.cin, self.cout, self.groups, self.p = in_channels, out_channels, num_groups, dropout_prob
 
     # temb: bf16 [B, time_emb_dim] (pre-SiLU)
     def _fwd(self, x, temb, out=None):
+        if self.use_film:
+            return self._fwd_film(x, temb, out)
         lin = self.time_mlp[1]
         B = x.shape[0]
         tp = torch.empty((B, self.cout), dtype=torch.float32, device=x.device)
@@ -309,13 +356,25 @@ class ResBlock(HipModule):
             y = K.conv3x3(h, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out, norm_in=n2)
         else:
             y = K.conv3x3(g2, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out)
-        return y, (x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed)
+        return y, (x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed, None)
+
+    def _fwd_film(self, x, temb, out=None):
+        """use_film=True (unet.py:96-98): h = dropout(gamma * conv1(..) + beta) instead of conv1(..) + time projection."""
+        p = self.p if self.training else 0.0
+        seed = next(_SEED) if p > 0 else 0
+        g1, st1 = K.gn_silu_fwd(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
+        h0 = K.conv3x3(g1, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1))
+        h, s_film = self.film_layer._fwd(h0, temb, p, seed)
+        g2, st2 = K.gn_silu_fwd(h, self.norm2.weight.detach(), self.norm2.bias.detach(), self.groups)
+        sk = x if isinstance(self.skip, nn.Identity) else K.gemm(x, PW.of(self.skip).fwd, self.cout, bias=_b(self.skip))
+        y = K.conv3x3(g2, PW.of(self.conv2).fwd, self.cout, bias=_b(self.conv2), res=sk, out=out)
+        return y, (x, temb, (g1, None), st1, h, (g2, None), st2, p, seed, s_film)
 
     def _bwd(self, dy, saved, g: Grads, dts=None, need_dx=True):
         """Returns (dx, dts): dts = accumulated gradient wrt silu(temb), bf16 [B, temb_dim]."""
-        x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed = saved
+        x, temb, (g1, n1), st1, h, (g2, n2), st2, p, seed, s_film = saved
         B = x.shape[0]
-        lin = self.time_mlp[1]
+        lin = None if self.use_film else self.time_mlp[1]
         d_g2 = K.conv3x3(dy, PW.of(self.conv2).bwd, self.cout)
         if g2 is None:   # folded GroupNorm: the weight gradient re-normalises h while staging, as the forward conv did
             K.wgrad_side(h, dy, g.of(self.conv2.weight), g.of(self.conv2.bias), norm_in=n2)
@@ -329,18 +388,23 @@ class ResBlock(HipModule):
         dtp = torch.zeros((B, self.cout), dtype=torch.float32, device=x.device)
         dh = K.gn_silu_bwd(h, d_g2, self.norm2.weight.detach(), self.norm2.bias.detach(), st2, self.groups,
                            g.of(self.norm2.weight), g.of(self.norm2.bias), drop_p=p, drop_seed=seed, colsum_out=dtp)
-        dtp16 = K.batchsum2_cast(dtp, g.of(self.conv1.bias), g.of(lin.bias))   # both bias gradients + the bf16 operand
-        K.wgrad_side(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
-        d_this = torch.empty((B, temb.shape[-1]), dtype=torch.float32, device=x.device)
-        K.gemm(dtp16, PW.of(lin).bwd, temb.shape[-1], out_f32=d_this)
+        if self.use_film:   # dh is the gradient of the FiLM output; dtp = its per-(sample, channel) sums = dbeta
+            dh, d_this = self.film_layer._bwd(dh, dtp, s_film, g)
+            conv1_bias_grad = g.of(self.conv1.bias)
+        else:
+            dtp16 = K.batchsum2_cast(dtp, g.of(self.conv1.bias), g.of(lin.bias))   # both bias gradients + the bf16 operand
+            K.wgrad_side(temb, dtp16, g.of(lin.weight), None, taps=1, act_silu_in=True)
+            d_this = torch.empty((B, temb.shape[-1]), dtype=torch.float32, device=x.device)
+            K.gemm(dtp16, PW.of(lin).bwd, temb.shape[-1], out_f32=d_this)
+            conv1_bias_grad = None
         if dts is None:
             dts = d_this
         else:  # fp32 accumulation across the ResBlocks (batchsum with one "batch" row == axpy)
             K.batchsum(d_this.view(1, -1), dts.view(-1))
         if g1 is None:
-            K.wgrad_side(x, dh, g.of(self.conv1.weight), None, norm_in=n1)
+            K.wgrad_side(x, dh, g.of(self.conv1.weight), conv1_bias_grad, norm_in=n1)
         else:
-            K.wgrad_side(g1, dh, g.of(self.conv1.weight), None)
+            K.wgrad_side(g1, dh, g.of(self.conv1.weight), conv1_bias_grad)
         dx = None
         if need_dx:
             d_g1 = K.conv3x3(dh, PW.of(self.conv1).bwd, self.cin)

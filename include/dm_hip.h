@@ -206,6 +206,18 @@ int dm_add_bf16(const void* a, long lda, const void* b, long ldb, void* out, lon
 /* dx = dy * silu'(x): backward of the head's nn.SiLU (unet.py:356). */
 int dm_silu_bwd_bf16(const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, long P, int C,
                      dm_stream_t stream);
+/* FiLM conditioning of a ResBlock (FiLMLayer.forward, unet.py:23-42, then nn.Dropout, unet.py:105):
+ * out[b][p][c] = dropout(gamma[b][c] * h[b][p][c] + beta[b][c]).  gamma_beta: fp32 [B, 2C], one row [gamma | beta] per
+ * sample = the output of film_mlp (unet.py:32-35).  The dropout mask is the one dm_gn_silu_bwd regenerates from
+ * (drop_seed, pixel, channel). */
+int dm_film_fwd(const void* h, long ldh, const float* gamma_beta, void* out, long ldo, int B, int HW, int C,
+                float drop_p, unsigned long long drop_seed, dm_stream_t stream);
+/* Backward of the same: dh0 = gamma * dh, and dgamma_partials[chunk][b][c] = the chunk's sum over pixels of dh * h0
+ * (fp32 [dm_film_bwd_chunks(HW), B, C]; the caller sums the chunks in order -- no atomics).  dbeta is the per-(sample,
+ * channel) sum of dh, which dm_gn_silu_bwd already returns (dx_colsum). */
+int dm_film_bwd_chunks(int HW);
+int dm_film_bwd(const void* dh, long lddh, const void* h0, long ldh, const float* gamma_beta, void* dh0, long ldo,
+                float* dgamma_partials, int B, int HW, int C, dm_stream_t stream);
 /* out[b][c] (=|+=) sum over the batch's rows of x[row][c]  (bias / time-projection gradients). */
 int dm_colsum_bf16(const void* x, long ldx, float* out, int nbatch, int rows_per_batch, int C, int accumulate,
                    dm_stream_t stream);

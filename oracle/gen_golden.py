@@ -63,8 +63,8 @@ def save(name, **arrs):
 
 
 # ----------------------------------------------------------------- module goldens
-def gen_resblock(tag, cin, cout, hw, B=2):
-    m = ref_unet.ResBlock(cin, cout, 256, 8, 0.0).eval()
+def gen_resblock(tag, cin, cout, hw, B=2, use_film=False):
+    m = ref_unet.ResBlock(cin, cout, 256, 8, 0.0, use_film=use_film).eval()
     load_cf(m)
     x = _rt((B, cin, hw, hw), 0.3).requires_grad_()
     te = _rt((B, 256), 1.1).requires_grad_()
@@ -240,6 +240,16 @@ def main():
     gen_unet_init("stl10_init_noctx", stl, 2, 48, None)
     gen_unet_init("mnist_init", mn, 4, 32, "labels")
     gen_ldm()
+    gen_film()
+
+
+def gen_film():
+    """use_film=True (unet.py:9-42,82-84,96-98) through the real reference: two ResBlocks and the STL10 UNet at the
+    reference-default init.  Run alone with `python3 oracle/gen_golden.py film`."""
+    gen_resblock("film_id64", 64, 64, 16, use_film=True)
+    gen_resblock("film_skip64_128", 64, 128, 8, use_film=True)
+    stl = dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0, time_steps=1000, use_film=True)
+    gen_unet_init("stl10_film_init", stl, 2, 32, "clip")
 
 
 def gen_ldm():
@@ -255,4 +265,7 @@ def gen_ldm():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["film"]:
+        gen_film()
+    else:
+        main()

@@ -50,6 +50,7 @@ class UNetSpec:
     use_cross_attention: bool = True
     context_dim: Optional[int] = None
     time_emb_dim: int = 256
+    use_film: bool = False
 
     @property
     def num_layers(self) -> int:
@@ -87,8 +88,12 @@ def param_shapes(spec: UNetSpec) -> "Dict[str, tuple]":
         if cin != cout:
             out[p + "res_block.skip.weight"] = (cout, cin, 1, 1)
             out[p + "res_block.skip.bias"] = (cout,)
-        out[p + "res_block.time_mlp.1.weight"] = (cout, temb)
-        out[p + "res_block.time_mlp.1.bias"] = (cout,)
+        if spec.use_film:   # unet.py:82-84 (FiLMLayer, unet.py:18-21)
+            out[p + "res_block.film_layer.film_mlp.1.weight"] = (2 * cout, temb)
+            out[p + "res_block.film_layer.film_mlp.1.bias"] = (2 * cout,)
+        else:
+            out[p + "res_block.time_mlp.1.weight"] = (cout, temb)
+            out[p + "res_block.time_mlp.1.bias"] = (cout,)
         if spec.Attentions[i]:
             out[p + "attention.linear_qkv.weight"] = (3 * cout, cout)
             out[p + "attention.linear_out.weight"] = (cout, cout)
@@ -223,11 +228,17 @@ def _gn_silu(x: Tensor, w: Tensor, b: Tensor, groups: int) -> Tensor:
 
 def res_block(sd, p: str, x: Tensor, temb: Tensor, groups: int, drop_p: float = 0.0,
               train: bool = False) -> Tensor:
-    """unet.py:92-108 (use_film=False branch)."""
+    """unet.py:92-108; the FiLM branch (unet.py:96-98, FiLMLayer.forward unet.py:23-42) is taken when the state dict
+    holds a film_layer."""
     h = F.conv2d(_gn_silu(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], groups),
                  _w(sd[p + "conv1.weight"]), sd[p + "conv1.bias"], padding=1)
-    tp = F.linear(F.silu(temb), _w(sd[p + "time_mlp.1.weight"]), sd[p + "time_mlp.1.bias"])
-    h = h + tp[:, :, None, None]
+    if (p + "film_layer.film_mlp.1.weight") in sd:
+        gb = F.linear(F.silu(temb), _w(sd[p + "film_layer.film_mlp.1.weight"]), sd[p + "film_layer.film_mlp.1.bias"])
+        gamma, beta = gb.chunk(2, dim=1)
+        h = gamma[:, :, None, None] * _q(h) + beta[:, :, None, None]
+    else:
+        tp = F.linear(F.silu(temb), _w(sd[p + "time_mlp.1.weight"]), sd[p + "time_mlp.1.bias"])
+        h = h + tp[:, :, None, None]
     h = _q(F.dropout(h, drop_p, training=train))
     h = F.conv2d(_gn_silu(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"], groups),
                  _w(sd[p + "conv2.weight"]), sd[p + "conv2.bias"], padding=1)

@@ -416,6 +416,39 @@ def test_gn_silu_bwd_fused_column_sums():
         assert torch.allclose(cs, ref, rtol=1e-4, atol=1e-3), float((cs - ref).abs().max())
 
 
+def test_film_fwd_bwd_and_dropout_words(K):
+    """dm_film_fwd / dm_film_bwd (FiLMLayer.forward, reference unet.py:32-42, + the Dropout of unet.py:105) against the
+    torch statement; the dropout word of an element is the one dm_conv3x3's epilogue draws for (seed, pixel, channel) --
+    which is also what dm_gn_silu_bwd regenerates in the backward."""
+    for B, H, W, C in ((2, 12, 12, 64), (3, 72, 72, 128), (2, 8, 8, 1024), (1, 20, 36, 192)):
+        h0 = rnd(B, H, W, C, seed=1).to(torch.bfloat16)
+        gb = rnd(B, 2 * C, seed=2)
+        gamma, beta = gb[:, None, None, :C], gb[:, None, None, C:]
+        out = K.film_fwd(h0, gb)
+        ref = gamma.double() * h0.double() + beta.double()   # (the kernel contracts to one fma: compare to one bf16 ulp)
+        assert float(((out.double() - ref).abs() / (ref.abs() + 1e-2)).max()) < 2 ** -8
+        dh = rnd(B, H, W, C, seed=3).to(torch.bfloat16)
+        dh0, dgamma = K.film_bwd(dh, h0, gb)
+        assert torch.equal(dh0, (gamma * dh.float()).to(torch.bfloat16))
+        assert_close(dgamma, (dh.float() * h0.float()).sum(dim=(1, 2)), 1e-5, "dgamma", atol_frac=1e-5)
+        d2 = K.film_bwd(dh, h0, gb)[1]
+        assert torch.equal(d2, dgamma), "dgamma is not run-to-run deterministic"
+    # dropout: the same elements are dropped as by the conv epilogue with the same seed, survivors scaled by 1/keep
+    B, H, W, C = 2, 16, 16, 64
+    x = nhwc(q16(rnd(B, C, H, W, seed=4)))
+    wp = K.pack_weight(rnd(C, C, 3, 3, seed=5, scale=0.05))
+    y0 = K.conv3x3(x, wp, C)
+    y1 = K.conv3x3(x, wp, C, drop_p=0.3, drop_seed=99)
+    unit = torch.cat([torch.ones(B, C), torch.zeros(B, C)], 1).to(dev())
+    f1 = K.film_fwd(y0, unit, 0.3, 99)
+    live = y0 != 0
+    assert torch.equal((y1 == 0) & live, (f1 == 0) & live)
+    keep = float(((f1 != 0) & live).sum()) / float(live.sum())
+    assert abs(keep - 0.7) < 0.02, keep
+    kept = (f1 != 0) & live
+    assert_close(f1[kept].float(), y0[kept].float() / 0.7, 1e-2, "kept values")
+
+
 def test_batchsum2_cast(K):
     """One pass for a ResBlock's per-(sample, channel) sums: both bias gradients (+=) and the bf16 copy."""
     for B, C in ((64, 64), (5, 1024), (3, 72)):

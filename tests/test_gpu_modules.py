@@ -37,11 +37,12 @@ def check_param_grads(mod, g, tol=TOL, skip=()):
         assert_close(p.grad, g["g." + n], tol, n)
 
 
-@pytest.mark.parametrize("tag,cin,cout", [("id64", 64, 64), ("skip64_128", 64, 128)])
+@pytest.mark.parametrize("tag,cin,cout", [("id64", 64, 64), ("skip64_128", 64, 128),
+                                          ("film_id64", 64, 64), ("film_skip64_128", 64, 128)])
 def test_resblock_vs_reference(tag, cin, cout):
     from diffusion_model_amd.unet import ResBlock
     g = load_golden(f"resblock_{tag}")
-    m = fill(ResBlock(cin, cout, 256, 8, 0.0))
+    m = fill(ResBlock(cin, cout, 256, 8, 0.0, use_film=tag.startswith("film")))
     y, (x, te) = run(m, g, ["x", "temb"])
     assert_close(y, g["y"], TOL, "y")
     assert_close(x.grad, g["gx"], TOL, "gx")
@@ -121,6 +122,7 @@ def test_full_unet_vs_reference(tag, spec_kw):
 LDM_KW = dict(Channels=[256, 256, 512, 1024, 512], Attentions=[False, True, True, False], input_channels=4,
               output_channels=4, context_dim=512, dropout_prob=0.0)   # reference utils.py:145-156
 INIT_CASES = [("stl10_init", STL, "clip"), ("stl10_init_noctx", STL, None),
+              ("stl10_film_init", dict(STL, use_film=True), "clip"),   # reference unet.py:9-42,82-84,96-98
               ("mnist_init", dict(Attentions=[False] * 6, dropout_prob=0.0), "labels"),
               ("ldm_init", LDM_KW, "clip"), ("ldm_init_noctx", LDM_KW, None)]
 

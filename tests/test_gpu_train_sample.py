@@ -30,14 +30,15 @@ def make_model(seed=0, dropout=0.0, base=None):
     return m.to(dev()), sd
 
 
-@pytest.mark.parametrize("variant", ["stl10", "latent"])
+@pytest.mark.parametrize("variant", ["stl10", "latent", "film"])
 def test_train_step_matches_oracle(variant):
     """``latent``: the same step on the reference's LDM configuration (utils.py:145-156) over 4x32x32 latents (SURVEY 8f
     item 3) -- q-sample, forward, weighted loss, backward, accumulation, clip, AdamW, EMA against the oracle."""
     from diffusion_model_amd.ema import ModelEmaV2
     from diffusion_model_amd.trainer import Trainer, lr_lambda
     from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
-    base = STL if variant == "stl10" else LDM_CFG
+    # ``film``: use_film=True (reference unet.py:9-42,82-84,96-98) through the same step
+    base = {"stl10": STL, "latent": LDM_CFG, "film": dict(STL, use_film=True)}[variant]
     CH = base["input_channels"]
     model, sd0 = make_model(base=base)
     model.train()  # dropout_prob = 0: train mode is deterministic
@@ -113,10 +114,12 @@ def test_train_step_matches_oracle(variant):
     assert_close(y, ref, 2e-2, "forward after the optimizer step")
 
 
-def test_dropout_train_mode_statistics():
+@pytest.mark.parametrize("film", [False, True])
+def test_dropout_train_mode_statistics(film):
     """dropout_prob=0.1 in train mode: stochastic (counter RNG), so only invariants can be checked:
-    different draws differ, eval is deterministic, and the expected output stays close to eval."""
-    model, _ = make_model(dropout=0.1)
+    different draws differ, eval is deterministic, and the expected output stays close to eval.
+    ``film``: the ResBlock dropout follows the FiLM modulation (dm_film_fwd draws the mask)."""
+    model, _ = make_model(dropout=0.1, base=dict(STL, use_film=True) if film else None)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 3, 32, 32, generator=g).to(dev())
     ctx = torch.nn.functional.normalize(torch.randn(2, 512, generator=g), dim=-1).to(dev())

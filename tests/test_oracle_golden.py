@@ -62,7 +62,8 @@ def test_gn_silu():
     assert_close(gb, g["g.bias"], FP32, "gb")
 
 
-@pytest.mark.parametrize("tag,cin,cout", [("id64", 64, 64), ("skip64_128", 64, 128)])
+@pytest.mark.parametrize("tag,cin,cout", [("id64", 64, 64), ("skip64_128", 64, 128),
+                                          ("film_id64", 64, 64), ("film_skip64_128", 64, 128)])
 def test_resblock(tag, cin, cout):
     g = load_golden(f"resblock_{tag}")
     shapes = {k[2:]: tuple(v.shape) for k, v in g.items() if k.startswith("g.")}
@@ -71,7 +72,10 @@ def test_resblock(tag, cin, cout):
              "norm1.bias", "norm2.weight", "norm2.bias"]
     if cin != cout:
         order += ["skip.weight", "skip.bias"]
-    order += ["time_mlp.1.weight", "time_mlp.1.bias"]
+    if tag.startswith("film"):   # use_film=True (reference unet.py:82-84)
+        order += ["film_layer.film_mlp.1.weight", "film_layer.film_mlp.1.bias"]
+    else:
+        order += ["time_mlp.1.weight", "time_mlp.1.bias"]
     sd = {k: v.requires_grad_() for k, v in _sd({k: shapes[k] for k in order}).items()}
     x = g["x"].clone().requires_grad_()
     te = g["temb"].clone().requires_grad_()
@@ -165,3 +169,39 @@ def test_full_unet(tag, spec_kw, hw):
     for k in g:
         if k.startswith("gf."):
             assert_close(dict(zip(names, grads[1:]))[k[3:]], g[k], FP32, k)
+
+
+def test_full_unet_film_reference_init():
+    """use_film=True through the whole network (reference unet.py:9-42,82-84,96-98), reference-default init under
+    torch.manual_seed(0): the drop-in module's constructor (host code, no kernel runs) reproduces the reference's
+    weights -- checked by the stored per-tensor norms -- and the oracle reproduces the real reference's output and
+    gradients on them."""
+    from diffusion_model_amd.unet import UNET
+    g = load_golden("unet_stl10_film_init")
+    kw = dict(input_channels=3, output_channels=3, context_dim=512, dropout_prob=0.0, use_film=True)
+    torch.manual_seed(0)
+    m = UNET(**kw)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        m.output_conv.weight.copy_(torch.randn(m.output_conv.weight.shape, generator=gen) * 0.05)
+    spec = oref.UNetSpec(**kw)
+    assert list(m.state_dict()) == list(oref.param_shapes(spec))
+    for k, v in m.state_dict().items():
+        assert float(torch.linalg.vector_norm(v)) == pytest.approx(float(g["wn." + k]), rel=1e-6), k
+    sd = {k: v.detach().clone().requires_grad_() for k, v in m.state_dict().items()}
+    x = g["x"].clone().requires_grad_()
+    y = oref.unet_forward(sd, spec, x, g["t"], g["ctx"])
+    assert_close(y, g["y"], FP32, "y")
+    names = list(sd)
+    grads = torch.autograd.grad((y * g["G"]).sum(), [x] + [sd[k] for k in names], allow_unused=True)
+    assert_close(grads[0], g["gx"], FP32, "gx")
+    gmax = max(float(v) for k, v in g.items() if k.startswith("gn."))
+    for k, gg in zip(names, grads[1:]):
+        if "gn." + k not in g:
+            continue
+        ref_n = float(g["gn." + k])
+        if ref_n < 1e-6 * gmax:
+            continue
+        assert float(torch.linalg.vector_norm(gg)) == pytest.approx(ref_n, rel=2e-4), k
+        if "gf." + k in g:
+            assert_close(gg, g["gf." + k], 2e-4, k, atol_frac=2e-4)
