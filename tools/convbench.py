@@ -88,7 +88,12 @@ WG = [("wgrad L1.conv 64->64@96", 0, 96, 64, 64), ("wgrad L2.conv2 128->128@48",
       ("wgrad late1 128->64@96", 0, 96, 128, 64), ("wgrad L1.down s2 64->64", 1, 96, 64, 64),
       ("wgrad gemm L2.qkv 128->384 M=147k", "g", 147456, 128, 384),
       ("wgrad gemm L4.conv1x1 128->64 M=590k", "g", 589824, 128, 64),
-      ("wgrad gemm L1.to_q 64->64 M=590k", "g", 589824, 64, 64)]
+      ("wgrad gemm L1.to_q 64->64 M=590k", "g", 589824, 64, 64),
+      ("wgrad gemm L2.skip 64->128 M=147k", "g", 147456, 64, 128),
+      ("wgrad gemm L2.out 128->128 M=147k", "g", 147456, 128, 128),
+      ("wgrad gemm L4.skip 256->128 M=147k", "g", 147456, 256, 128),
+      ("wgrad gemm L3.qkv 256->768 M=37k", "g", 36864, 256, 768),
+      ("wgrad gemm L3.out 256->256 M=37k", "g", 36864, 256, 256)]
 for name, mode, H, cin, cout in WG:
     if args.only and args.only not in name:
         continue
