@@ -51,7 +51,8 @@ class AttnArgs(C.Structure):
                 ("dq", c_void_p), ("lddq", c_long), ("dk", c_void_p), ("lddk", c_long),
                 ("dv", c_void_p), ("lddv", c_long), ("delta", c_void_p),
                 ("B", c_int), ("heads", c_int), ("Nq", c_int), ("Nk", c_int), ("hd", c_int),
-                ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_ulonglong)]
+                ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_ulonglong),
+                ("workspace", c_void_p), ("ws_bytes", c_long)]
 
 
 _SIGS = {
@@ -79,6 +80,7 @@ _SIGS = {
                                c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_attn_bwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "dm_attn_bwd_workspace_bytes": (c_long, [c_int] * 5),
     "dm_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "dm_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),

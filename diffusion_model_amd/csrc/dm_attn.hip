@@ -652,6 +652,215 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
   }
 }
 
+// ---------------------------------------------------------------- fused backward (head dim 16, 2304 keys per head)
+// attn_bwd_kv_kernel and attn_bwd_q_kernel each recompute the probabilities (exp2, dropout compare / selects): with
+// head dim 16 that VALU work IS the run time of both.  This kernel computes them once.  A workgroup of 8 waves owns
+// HALF the keys of one (batch, head): every wave keeps 9 key tiles (144 keys) resident in registers -- the scaled
+// hi/lo key fragment for the score MFMA, V^T for dP, K^T for dQ, and the dK^T / dV^T accumulators -- and the workgroup
+// sweeps all queries in blocks of 64 (staged as in attn_bwd_kv_kernel).  Per (16 queries x 16 keys):
+//   S, dP (MFMA) -> P, dS (VALU, once) -> dV^T += dO^T P, dK^T += Q^T dS  (P, dS are already B operands), and
+//   dQ^T += K^T dS^T, whose B operand is the TRANSPOSE of the tile: 8 bytes per lane through a per-wave LDS tile
+//   and one ds_read_b64_tr_b16 back.
+// The dQ^T partial of a wave covers its 144 keys; the 8 waves' partials are summed in wave order through LDS once per
+// 64-query block, and the two workgroups of a (batch, head) leave two fp32 partial arrays that attn_dq_merge_kernel
+// adds (fixed order everywhere: bit-reproducible).  All 16x16x16 MFMAs except the score (hi/lo split in k-slots 16-31).
+constexpr int FB_KT = 9;                       // key tiles (16 keys) per wave
+constexpr int FB_KEYS = FB_KT * 16 * 8;        // keys per workgroup (1152)
+
+__device__ __forceinline__ s16x4 tr16(const char* a) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pair(float a, float b) {   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ s16x4 pack4(const float (&v)[4]) {
+  return __builtin_bit_cast(s16x4, u32x2{cvt_pair(v[0], v[1]), cvt_pair(v[2], v[3])});
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p, float* __restrict__ dq_part) {
+  constexpr int DT = 1;
+  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);
+  __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
+  __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];
+  constexpr int ROFF = 72;                                       // see attn_bwd_kv_kernel
+  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][ROFF + 64];
+  __shared__ __attribute__((aligned(16))) char sT[8][1024];      // per-wave [16 keys][16 queries] bf16 transpose tiles (two, alternating)
+  __shared__ __attribute__((aligned(16))) float sDQ[8][64 * 16]; // per-wave dQ partial of the current query block
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int gk = g & 1;
+  const int half = blockIdx.x, bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
+  const int key0 = half * FB_KEYS + wave * (FB_KT * 16);         // first key of this wave
+  const float c = p.scale * LOG2E;
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  const float keepf = DROP ? p.keep : 1.f;
+
+  bf16x8 kf[FB_KT];          // c * K, hi (k-slots 0-15) / lo (16-31): B operand of the score MFMA
+  s16x4 vf[FB_KT], kq[FB_KT];  // V^T (B operand of dP), K^T (A operand of dQ^T)
+  f32x4 dkT[FB_KT], dvT[FB_KT];
+  uint32_t cwl[FB_KT];
+#pragma unroll
+  for (int kt = 0; kt < FB_KT; ++kt) {
+    const int key = key0 + kt * 16 + li;
+    bf16x8 unused;
+    load_scaled_frag<DT>(p.k, p.ldk, kbase + key, true, hoff, p.hd, g, c, kf[kt], unused);
+    vf[kt] = *reinterpret_cast<const s16x4*>(p.v + (kbase + key) * p.ldv + hoff + 4 * g);
+    bf16x4 kc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kc[j] = p.k[(kbase + key0 + kt * 16 + 4 * g + j) * p.ldk + hoff + li];
+    kq[kt] = __builtin_bit_cast(s16x4, kc);
+    dkT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cwl[kt] = 0u;
+    if constexpr (DROP) {
+      const uint32_t cw = dm_attn_colword(seed_eff, (uint32_t)key >> 1) & M15;
+      cwl[kt] = (key & 1) ? (cw >> 16) : cw;
+    }
+  }
+  const int rpar = (li & 1) * ROFF;   // key parity = lane parity (tiles start at multiples of 16)
+  const int nqb = p.Nq / 64;
+
+  const Stager<DT> stg = make_stager<DT>(p.q, p.ldq, p.d_o, p.lddo, qbase, p.Nq, hoff, p.hd, tid & 255, wave & 3);
+  const bool stager = wave < 4;       // waves 0-3 stage the Q / dO blocks (one 16-byte piece per thread)
+  struct Regs { Stage<DT> st; float l, d; uint32_t rs; bool ok; };
+  auto fetch = [&](int qb, Regs& r) {
+    if (stager) stage_load<DT>(r.st, stg, qb);
+    if (wave == 0) {
+      const int q = qb * 64 + tid;
+      const bool ok = q < p.Nq;
+      const long li_ = (long)bh * p.Nq + (ok ? q : 0);
+      r.l = p.lse[li_]; r.d = p.delta[li_]; r.ok = ok;   // raw values only (see attn_bwd_kv_kernel)
+      if (DROP) r.rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q)) & M15;
+    }
+  };
+  auto put = [&](int buf, const Regs& r) {
+    if (stager) stage_store<DT>(r.st, sQb[buf], sOb[buf], tid);
+    if (wave == 0) {
+      sLb[buf][tid] = r.ok ? -(r.l * LOG2E) : -1e30f;
+      sDb[buf][tid] = r.ok ? -r.d * keepf : 0.f;
+      if (DROP) { sRb[buf][tid] = r.rs; sRb[buf][ROFF + tid] = r.rs >> 16; }
+    }
+  };
+  Regs r0{}, r1{};
+  fetch(0, r0);
+  if (nqb > 1) fetch(1, r1); else r1 = r0;
+  put(0, r0);
+  __syncthreads();
+  char* sTw = sT[wave];
+  const int qq = li >> 2, pp = li & 3;
+  float* part = dq_part + (((long)half * p.B * p.H + bh) * p.Nq) * 16;
+  auto block = [&](int qb, Regs& r_free, const Regs& r_next) {
+    fetch(qb + 2, r_free);
+    const char* sQ = sQb[qb & 1];
+    const char* sO = sOb[qb & 1];
+    const float* sL = sLb[qb & 1];
+    const float* sD = sDb[qb & 1];
+#pragma unroll 1
+    for (int qt = 0; qt < 4; ++qt) {
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + (qt * 16 + li) * RS + gk * 16);
+      const s16x4 da = *reinterpret_cast<const s16x4*>(sO + (qt * 16 + li) * RS + g * 8);
+      const f32x4 L4 = *reinterpret_cast<const f32x4*>(sL + qt * 16 + 4 * g);
+      const f32x4 D4 = *reinterpret_cast<const f32x4*>(sD + qt * 16 + 4 * g);
+      u32x4 R4 = {0u, 0u, 0u, 0u};
+      if constexpr (DROP) R4 = *reinterpret_cast<const u32x4*>(sRb[qb & 1] + rpar + qt * 16 + 4 * g);
+      const int toff = (qt * 16 + 4 * g + qq) * RS + pp * 8;
+      const s16x4 doT = tr16(sO + toff);   // [d x 16 queries]: A operand of dV^T
+      const s16x4 qT = tr16(sQ + toff);    //                   A operand of dK^T
+      f32x4 dq4 = {0.f, 0.f, 0.f, 0.f};
+      // software pipeline over the key tiles: the score / dP MFMAs of tile kt + 1 are issued before the VALU work of
+      // tile kt (their results are not waited for), and the transposed dS of tile kt is consumed one tile later
+      // (two alternating LDS tiles), so neither the MFMA nor the LDS round trip is exposed
+      f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[0], L4, 0, 0, 0);       // c*s - LSE
+      f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(da, vf[0], D4, 0, 0, 0);    // dP - delta*keep
+      s16x4 dsT = {0, 0, 0, 0};
+#pragma unroll
+      for (int kt = 0; kt < FB_KT; ++kt) {
+        f32x4 sn = s, dpn = dp;
+        if (kt + 1 < FB_KT) {
+          sn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt + 1], L4, 0, 0, 0);
+          dpn = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(da, vf[kt + 1], D4, 0, 0, 0);
+        }
+        float u[4], w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[r]);
+          float uu = pv, t = dp[r];
+          if constexpr (DROP) {
+            const bool keep = keep15(R4[r] ^ cwl[kt], 0, p.t15);
+            uu = keep ? pv : 0.f;
+            t = keep ? t : D4[r];
+          }
+          u[r] = uu;
+          w[r] = pv * t;
+        }
+        const s16x4 pB = pack4(u), dsB = pack4(w);
+        if (kt > 0) dq4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kq[kt - 1], dsT, dq4, 0, 0, 0);
+        dvT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doT, pB, dvT[kt], 0, 0, 0);
+        dkT[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, dsB, dkT[kt], 0, 0, 0);
+        // dS tile [query 4g+r][key li] -> LDS as T[key][query]; the transposing read returns, for query li, keys 4g..4g+3
+        char* tt = sTw + (kt & 1) * 512;
+        *reinterpret_cast<s16x4*>(tt + li * 32 + g * 8) = dsB;
+        dsT = tr16(tt + (4 * g + qq) * 32 + pp * 8);
+        s = sn; dp = dpn;
+      }
+      dq4 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kq[FB_KT - 1], dsT, dq4, 0, 0, 0);
+      *reinterpret_cast<f32x4*>(&sDQ[wave][(qt * 16 + li) * 16 + 4 * g]) = dq4;   // dQ^T: rows d = 4g.., column = query li
+    }
+    if (qb + 1 < nqb) put((qb + 1) & 1, r_next);
+    __syncthreads();
+    // the 8 waves' partials, in wave order -> this workgroup's fp32 partial of dQ (64 queries x 16 dims, coalesced)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i;
+      float a = sDQ[0][idx];
+#pragma unroll
+      for (int wv = 1; wv < 8; ++wv) a += sDQ[wv][idx];
+      part[(long)qb * 1024 + idx] = a;
+    }
+    __syncthreads();
+  };
+  {
+    int qb = 0;
+    for (; qb + 1 < nqb; qb += 2) {
+      block(qb, r0, r1);
+      block(qb + 1, r1, r0);
+    }
+    if (qb < nqb) block(qb, r0, r1);
+  }
+  const float ik = DROP ? p.inv_keep : 1.f;
+#pragma unroll
+  for (int kt = 0; kt < FB_KT; ++kt) {
+    const int key = key0 + kt * 16 + li;
+    bf16x4 ok, ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ok[r] = (bf16)(dkT[kt][r] * (p.scale * ik)); ov[r] = (bf16)(dvT[kt][r] * ik); }
+    *reinterpret_cast<bf16x4*>(p.dk + (kbase + key) * p.lddk + hoff + 4 * g) = ok;
+    *reinterpret_cast<bf16x4*>(p.dv + (kbase + key) * p.lddv + hoff + 4 * g) = ov;
+  }
+}
+
+// dq = scale / keep * (partial of key half 0 + partial of key half 1); thread = (batch*head, query, 4 dims)
+__global__ __launch_bounds__(256) void attn_dq_merge_kernel(const AttnParams p, const float* __restrict__ part, float osc) {
+  const long n4 = (long)p.B * p.H * p.Nq * 4, hs = (long)p.B * p.H * p.Nq * 16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(part + i * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(part + hs + i * 4);
+    const int d4 = (int)(i & 3);
+    const long rq = i >> 2;
+    const int q = (int)(rq % p.Nq);
+    const int bh = (int)(rq / p.Nq);
+    const int b = bh / p.H, h = bh % p.H;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (bf16)((a[r] + b2[r]) * osc);
+    *reinterpret_cast<bf16x4*>(p.dq + ((long)b * p.Nq + q) * p.lddq + h * 16 + d4 * 4) = o;
+  }
+}
+
 // ---------------------------------------------------------------- few-token cross-attention
 // Nk <= 16 context tokens (the CLIP table gives exactly ONE): a 64-key flash tile would be >= 75 %
 // masked, so these kernels drop MFMA altogether.  HBM-bound: q / dO are read, o / dq written, once.
@@ -1202,7 +1411,17 @@ int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   return DM_OK;
 }
 
+bool fused_bwd_enabled() {   // DM_ATTN_BWD_FUSED=0: the two-kernel backward, for A/B measurements
+  static const bool on = [] { const char* e = getenv("DM_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 }  // namespace
+
+extern "C" long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd) {
+  if (hd == 16 && Nk == 2 * FB_KEYS && Nq % 64 == 0) return (long)2 * B * heads * Nq * 16 * 4;
+  return 0;
+}
 
 extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   AttnParams p{};
@@ -1310,6 +1529,22 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
       hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<128>, gk, dim3(256), 0, st, p);
       hipLaunchKernelGGL(attn_wide_bwd_q_kernel<128>, gqw, dim3(256), 0, st, p);
     }
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  // head dim 16 with 2304 keys per head (the 48x48 self-attention of the STL10 UNet): one pass over the scores
+  // instead of two (attn_bwd_fused_kernel), when the caller brought the workspace for the two fp32 dQ partials
+  if (p.hd == 16 && p.Nk == 2 * FB_KEYS && p.Nq % 64 == 0 && a->workspace &&
+      a->ws_bytes >= dm_attn_bwd_workspace_bytes(p.B, p.H, p.Nq, p.Nk, p.hd) && fused_bwd_enabled()) {
+    float* part = (float*)a->workspace;
+    dm_set_variant(p.thresh ? "attn_bwd_fused<DROP=1>" : "attn_bwd_fused<DROP=0>");
+    if (p.thresh) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(2, p.B * p.H), dim3(512), 0, st, p, part);
+    else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(2, p.B * p.H), dim3(512), 0, st, p, part);
+    DM_LAUNCH_CHECK();
+    long nb = ((long)p.B * p.H * p.Nq * 4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(attn_dq_merge_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const float*)part,
+                       p.scale * (p.thresh ? p.inv_keep : 1.f));
     DM_LAUNCH_CHECK();
     return DM_OK;
   }

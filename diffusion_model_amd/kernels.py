@@ -439,7 +439,7 @@ def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0.0, drop_seed=0):
+def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0.0, drop_seed=0, single_pass=True):
     B, Nq, Cc = q.shape
     Nk = k.shape[1]
     dq = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if dq is None else dq
@@ -452,6 +452,10 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     a.d_o, a.lddo = _p(d_o), _act(d_o, "d_o")
     a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
     a.delta = _p(delta)
+    nb = _lib.lib().dm_attn_bwd_workspace_bytes(B, heads, Nq, Nk, Cc // heads)
+    if nb > 0 and single_pass:   # single-pass backward: two fp32 partial copies of dq
+        ws = workspace(nb, q.device)
+        a.workspace, a.ws_bytes = _p(ws), ws.numel()
     check(_lib.lib().dm_attn_bwd(C.byref(a), _stream()), "dm_attn_bwd")
     return dq, dk, dv
 

@@ -180,6 +180,9 @@ typedef struct dm_attn_args {
                                      utils.py:145-156: fp32 VALU kernels) */
   float scale;                    /* 1/sqrt(hd) */
   float drop_p; unsigned long long drop_seed;
+  void* workspace; long ws_bytes; /* backward, optional: dm_attn_bwd_workspace_bytes() bytes of scratch.  With it, the shapes
+                                     that function returns > 0 for take the single-pass backward (probabilities computed
+                                     once for dq, dk and dv); without it (NULL) every shape runs the two-kernel backward */
 } dm_attn_args;
 /* Flash-style fused softmax(QK^T*scale)V on bf16 MFMA, online softmax, no N x N matrix in
  * memory.  Replaces F.scaled_dot_product_attention for self- and cross-attention
@@ -189,6 +192,8 @@ typedef struct dm_attn_args {
  * dq = dk = NULL (backward: only dv is produced).  Any other NULL is DM_ERR_ARG. */
 int dm_attn_fwd(const dm_attn_args* args, dm_stream_t stream);
 int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
+/* Scratch the single-pass backward wants for this shape (two fp32 partial copies of dq), or 0 when the shape has none. */
+long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd);
 
 /* ------------------------------------------------------------------ layout / elementwise */
 /* NCHW fp32 -> NHWC bf16, channels zero-padded to Cpad (UNET.forward entry, unet.py:344). */

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close
+from conftest import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -305,6 +305,31 @@ def test_attention_dropout_consistency(K, N, Nk, C):
     dq, dk, dv = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=1234)
     # sum_keys dV[key] = sum_q sum_k P_drop[q,k] = sum_q o[q]
     assert_close(dv.float().sum(1), o.float().sum(1), 2e-2, "dropout mass")
+
+
+@pytest.mark.parametrize("B,p", [(1, 0.0), (2, 0.1)])
+def test_attention_single_pass_backward_matches_two_kernel_backward(K, B, p):
+    """hd 16, 2304 keys (the UNet's 48x48 self-attention): dm_attn_bwd with the workspace takes attn_bwd_fused (the
+    probabilities are computed once for dq, dk, dv); without it, attn_bwd_kv + attn_bwd_q.  Same dropout words, same
+    arithmetic up to summation order: the two must agree far inside the bf16 output rounding, and the fused path must
+    be run-to-run bit-identical.  (Against torch autograd: test_attention_fwd_bwd[1-2304-2304-128].)"""
+    from diffusion_model_amd import _lib
+    heads, N, C = 8, 2304, 128
+    q = q16(rnd(B, N, C, seed=1)).to(torch.bfloat16)
+    k = q16(rnd(B, N, C, seed=2)).to(torch.bfloat16)
+    v = q16(rnd(B, N, C, seed=3)).to(torch.bfloat16)
+    d_o = q16(rnd(B, N, C, seed=4)).to(torch.bfloat16)
+    o, lse = K.attn_fwd(q, k, v, heads, drop_p=p, drop_seed=77)
+    a = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=77)
+    assert _lib.lib().dm_last_variant().decode().startswith("attn_bwd_fused")
+    b = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=77, single_pass=False)
+    assert _lib.lib().dm_last_variant().decode().startswith("attn_flash_bwd")
+    for name, x, y in zip(("dq", "dk", "dv"), a, b):
+        assert_close(x.float(), y.float(), 8e-3, name, atol_frac=4e-3)
+        assert rel_l2(x, y) < 3e-3, (name, rel_l2(x, y))
+    a2 = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=77)
+    for x, y in zip(a, a2):
+        assert torch.equal(x, y)
 
 
 # ------------------------------------------------------------------ layout / elementwise
