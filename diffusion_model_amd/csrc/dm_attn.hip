@@ -664,8 +664,7 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
 // The dQ^T partial of a wave covers its 144 keys; the 8 waves' partials are summed in wave order through LDS once per
 // 64-query block, and the two workgroups of a (batch, head) leave two fp32 partial arrays that attn_dq_merge_kernel
 // adds (fixed order everywhere: bit-reproducible).  All 16x16x16 MFMAs except the score (hi/lo split in k-slots 16-31).
-constexpr int FB_KT = 9;                       // key tiles (16 keys) per wave
-constexpr int FB_KEYS = FB_KT * 16 * 8;        // keys per workgroup (1152)
+constexpr int FB_NK = 2304;                    // keys per head this kernel family is built for
 
 __device__ __forceinline__ s16x4 tr16(const char* a) {
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -680,21 +679,28 @@ __device__ __forceinline__ s16x4 pack4(const float (&v)[4]) {
   return __builtin_bit_cast(s16x4, u32x2{cvt_pair(v[0], v[1]), cvt_pair(v[2], v[3])});
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p, float* __restrict__ dq_part) {
+// NW waves per workgroup, FB_KT key tiles (16 keys) per wave: a workgroup owns NW * FB_KT * 16 keys, and
+// FB_NK / that many workgroups (key splits) share one (batch, head).
+template <bool DROP, int NW, int FB_KT>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(const AttnParams p, float* __restrict__ dq_part) {
   constexpr int DT = 1;
+  constexpr int FB_KEYS = NW * FB_KT * 16;
   [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);
-  __shared__ __attribute__((aligned(16))) char sQb[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) char sOb[2][64 * RS];
-  __shared__ __attribute__((aligned(16))) float sLb[2][64], sDb[2][64];
   constexpr int ROFF = 72;                                       // see attn_bwd_kv_kernel
-  __shared__ __attribute__((aligned(16))) uint32_t sRb[2][ROFF + 64];
-  __shared__ __attribute__((aligned(16))) char sT[8][1024];      // per-wave [16 keys][16 queries] bf16 transpose tiles (two, alternating)
-  __shared__ __attribute__((aligned(16))) float sDQ[8][64 * 16]; // per-wave dQ partial of the current query block
+  extern __shared__ __attribute__((aligned(16))) char fb_smem[];
+  char (*sQb)[64 * RS] = reinterpret_cast<char (*)[64 * RS]>(fb_smem);                     // [2]
+  char (*sOb)[64 * RS] = reinterpret_cast<char (*)[64 * RS]>(fb_smem + 2 * 64 * RS);       // [2]
+  float (*sLb)[64] = reinterpret_cast<float (*)[64]>(fb_smem + 4 * 64 * RS);               // [2]
+  float (*sDb)[64] = reinterpret_cast<float (*)[64]>(fb_smem + 4 * 64 * RS + 512);         // [2]
+  uint32_t (*sRb)[ROFF + 64] = reinterpret_cast<uint32_t (*)[ROFF + 64]>(fb_smem + 4 * 64 * RS + 1024);   // [2]
+  constexpr int OFF_T = 4 * 64 * RS + 1024 + 2 * (ROFF + 64) * 4;
+  static_assert(OFF_T % 16 == 0, "alignment of the transpose tiles");
+  char (*sT)[1024] = reinterpret_cast<char (*)[1024]>(fb_smem + OFF_T);                    // [NW] two [16 keys][16 queries] bf16 tiles per wave
+  float (*sDQ)[64 * 16] = reinterpret_cast<float (*)[64 * 16]>(fb_smem + OFF_T + NW * 1024);   // [NW] per-wave dQ partial of the query block
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   const int gk = g & 1;
-  const int half = blockIdx.x, bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
-  const int key0 = half * FB_KEYS + wave * (FB_KT * 16);         // first key of this wave
+  const int split = blockIdx.x, bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * p.hd;
+  const int key0 = split * FB_KEYS + wave * (FB_KT * 16);         // first key of this wave
   const float c = p.scale * LOG2E;
   const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
   const float keepf = DROP ? p.keep : 1.f;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p,
   __syncthreads();
   char* sTw = sT[wave];
   const int qq = li >> 2, pp = li & 3;
-  float* part = dq_part + (((long)half * p.B * p.H + bh) * p.Nq) * 16;
+  float* part = dq_part + (((long)split * p.B * p.H + bh) * p.Nq) * 16;
   auto block = [&](int qb, Regs& r_free, const Regs& r_next) {
     fetch(qb + 2, r_free);
     const char* sQ = sQb[qb & 1];
@@ -812,13 +818,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p,
     }
     if (qb + 1 < nqb) put((qb + 1) & 1, r_next);
     __syncthreads();
-    // the 8 waves' partials, in wave order -> this workgroup's fp32 partial of dQ (64 queries x 16 dims, coalesced)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i;
+    // the waves' partials, in wave order -> this workgroup's fp32 partial of dQ (64 queries x 16 dims, coalesced)
+    for (int idx = tid; idx < 1024; idx += NW * 64) {
       float a = sDQ[0][idx];
 #pragma unroll
-      for (int wv = 1; wv < 8; ++wv) a += sDQ[wv][idx];
+      for (int wv = 1; wv < NW; ++wv) a += sDQ[wv][idx];
       part[(long)qb * 1024 + idx] = a;
     }
     __syncthreads();
@@ -843,12 +847,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const AttnParams p,
   }
 }
 
-// dq = scale / keep * (partial of key half 0 + partial of key half 1); thread = (batch*head, query, 4 dims)
-__global__ __launch_bounds__(256) void attn_dq_merge_kernel(const AttnParams p, const float* __restrict__ part, float osc) {
+// dq = scale / keep * (sum of the key splits' partials, in split order); thread = (batch*head, query, 4 dims)
+__global__ __launch_bounds__(256) void attn_dq_merge_kernel(const AttnParams p, const float* __restrict__ part, float osc,
+                                                            int nsplit) {
   const long n4 = (long)p.B * p.H * p.Nq * 4, hs = (long)p.B * p.H * p.Nq * 16;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(part + i * 4);
-    const f32x4 b2 = *reinterpret_cast<const f32x4*>(part + hs + i * 4);
+    f32x4 a = *reinterpret_cast<const f32x4*>(part + i * 4);
+    for (int sp = 1; sp < nsplit; ++sp) a += *reinterpret_cast<const f32x4*>(part + sp * hs + i * 4);
+    const f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
     const int d4 = (int)(i & 3);
     const long rq = i >> 2;
     const int q = (int)(rq % p.Nq);
@@ -1411,6 +1417,20 @@ int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
   return DM_OK;
 }
 
+template <bool DROP, int NW, int KT>
+int launch_fused(const AttnParams& p, float* part, hipStream_t st) {
+  constexpr int LDS = 4 * 64 * RS + 1024 + 2 * (72 + 64) * 4 + NW * 1024 + NW * 4096;
+  auto k = attn_bwd_fused_kernel<DROP, NW, KT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(FB_NK / (NW * KT * 16), p.B * p.H), dim3(NW * 64), LDS, st, p, part);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
 bool fused_bwd_enabled() {   // DM_ATTN_BWD_FUSED=0: the two-kernel backward, for A/B measurements
   static const bool on = [] { const char* e = getenv("DM_ATTN_BWD_FUSED"); return !(e && e[0] == '0'); }();
   return on;
@@ -1419,7 +1439,7 @@ bool fused_bwd_enabled() {   // DM_ATTN_BWD_FUSED=0: the two-kernel backward, fo
 }  // namespace
 
 extern "C" long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd) {
-  if (hd == 16 && Nk == 2 * FB_KEYS && Nq % 64 == 0) return (long)2 * B * heads * Nq * 16 * 4;
+  if (hd == 16 && Nk == FB_NK && Nq % 64 == 0) return (long)2 * B * heads * Nq * 16 * 4;   // two key splits
   return 0;
 }
 
@@ -1534,17 +1554,20 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
   }
   // head dim 16 with 2304 keys per head (the 48x48 self-attention of the STL10 UNet): one pass over the scores
   // instead of two (attn_bwd_fused_kernel), when the caller brought the workspace for the two fp32 dQ partials
-  if (p.hd == 16 && p.Nk == 2 * FB_KEYS && p.Nq % 64 == 0 && a->workspace &&
+  if (p.hd == 16 && p.Nk == FB_NK && p.Nq % 64 == 0 && a->workspace &&
       a->ws_bytes >= dm_attn_bwd_workspace_bytes(p.B, p.H, p.Nq, p.Nk, p.hd) && fused_bwd_enabled()) {
     float* part = (float*)a->workspace;
     dm_set_variant(p.thresh ? "attn_bwd_fused<DROP=1>" : "attn_bwd_fused<DROP=0>");
-    if (p.thresh) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(2, p.B * p.H), dim3(512), 0, st, p, part);
-    else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(2, p.B * p.H), dim3(512), 0, st, p, part);
-    DM_LAUNCH_CHECK();
+    // 8 waves x 9 key tiles, two key splits.  Measured against it (B=64, dropout 0.1): 12 waves x 4 tiles x 3 splits
+    // (168 VGPRs, 3 waves per SIMD) 1162 us and 16 x 3 x 3 (128 VGPRs) 1166 us against 1050 us -- the per-query-tile
+    // fixed work and the third dQ partial cost more than the extra waves hide
+    const int rc2 = p.thresh ? launch_fused<true, 8, 9>(p, part, st) : launch_fused<false, 8, 9>(p, part, st);
+    if (rc2 != DM_OK) return rc2;
+    const int nsplit = FB_NK / (8 * 9 * 16);
     long nb = ((long)p.B * p.H * p.Nq * 4 + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(attn_dq_merge_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const float*)part,
-                       p.scale * (p.thresh ? p.inv_keep : 1.f));
+                       p.scale * (p.thresh ? p.inv_keep : 1.f), nsplit);
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
