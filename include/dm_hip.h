@@ -32,7 +32,8 @@ typedef void* dm_stream_t;
 #define DM_ERR_TOO_LARGE (-3)   /* a size beyond an entry point's documented fixed maximum */
 
 /* ABI version / arch string ("gfx950").  Version 2 (round 2): dm_conv_args / dm_wgrad_args grew the trailing
- * norm_scale / norm_shift fields; callers built against version 1 must be rebuilt. */
+ * norm_scale / norm_shift fields.  Version 3: dm_attn_args grew the trailing workspace / ws_bytes fields and
+ * dm_attn_bwd_workspace_bytes, dm_film_fwd / dm_film_bwd were added.  Callers built against an older version must be rebuilt. */
 int dm_abi_version(void);
 const char* dm_target_arch(void);
 /* Text of the HIP error behind the calling thread's last DM_ERR_LAUNCH ("" if none). */
