@@ -220,6 +220,40 @@ def test_wgrad_linear_full_size(K, M, Kd, N):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)   # bit-reproducible
 
 
+def test_attention_backward_full_size_single_pass(K):
+    """The L2 self-attention of the B=64 step (8 heads x 16, 2304 tokens, dropout 0.1): dm_attn_bwd takes the single-pass
+    kernel (asserted through dm_last_variant) on the strided q / k / v views of the fused qkv buffer, and three samples
+    spread over the batch -- first, middle, last, i.e. different workgroups / dispatch rounds -- match torch autograd of
+    softmax(QK^T/sqrt(d)) at drop_p = 0; the dropout run (whose mask torch cannot reproduce) is compared, whole batch,
+    with the two-kernel backward, which draws the same mask words."""
+    from diffusion_model_amd import _lib
+    B, N, C, heads = 64, 2304, 128, 8
+    qkv = (rnd(B, N, 3 * C, seed=21) * 0.7).to(torch.bfloat16)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    d_o = (rnd(B, N, C, seed=22)).to(torch.bfloat16)
+    # ---- no dropout: against torch autograd on three samples
+    o, lse = K.attn_fwd(q, k, v, heads)
+    dq, dk, dv = K.attn_bwd(q, k, v, o, lse, d_o, heads)
+    assert _lib.lib().dm_last_variant().decode() == "attn_bwd_fused<DROP=0>"
+    for b in (0, 31, 63):
+        qq, kk, vv = (t[b:b + 1].float().reshape(1, N, heads, C // heads).transpose(1, 2).requires_grad_() for t in (q, k, v))
+        ref = F.scaled_dot_product_attention(qq, kk, vv)
+        gq, gk, gv = torch.autograd.grad(ref, [qq, kk, vv], d_o[b:b + 1].float().reshape(1, N, heads, C // heads).transpose(1, 2))
+        back = lambda t: t.transpose(1, 2).reshape(1, N, C)
+        assert_close(dq[b:b + 1].float(), back(gq), 1.5e-2, f"dq[{b}]")
+        assert_close(dk[b:b + 1].float(), back(gk), 1.5e-2, f"dk[{b}]")
+        assert_close(dv[b:b + 1].float(), back(gv), 1.5e-2, f"dv[{b}]")
+    # ---- dropout 0.1: against the two-kernel backward (same mask words), whole batch
+    o, lse = K.attn_fwd(q, k, v, heads, drop_p=0.1, drop_seed=5)
+    a = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=0.1, drop_seed=5)
+    assert _lib.lib().dm_last_variant().decode() == "attn_bwd_fused<DROP=1>"
+    b2 = K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=0.1, drop_seed=5, single_pass=False)
+    assert _lib.lib().dm_last_variant().decode() == "attn_flash_bwd<DT=1,DROP=1>"
+    for name, x, y in zip(("dq", "dk", "dv"), a, b2):
+        assert rel_l2(x, y) < 3e-3, (name, rel_l2(x, y))
+        assert_close(x.float(), y.float(), 8e-3, name, atol_frac=4e-3)
+
+
 def test_side_stream_workspace_growth_keeps_gradients(K):
     """The weight-gradient side stream's scratch buffer grows on first use at real shapes (> 1 MiB).  The buffer it
     replaces may still be in use by the wgrad queued before it; it must not be handed back to the allocator until the
