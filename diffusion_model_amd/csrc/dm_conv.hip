@@ -856,7 +856,13 @@ int launch_gemm_stream_v(const ConvParams& p, hipStream_t st) {
   }
   const int ntiles = (int)((p.M + 16 * MT - 1) / (16 * MT));  // wave tiles
   const int gy = p.Cout / (16 * NT);
-  int gx = 1024 / gy;  // up to four resident workgroups per CU in total (VGPR/LDS permitting)
+  // Workgroups in total: four per CU when every wave still gets four or more row tiles (M >= 256k rows), else two per
+  // CU -- each workgroup stages its whole weight slice first, and with 2.25 tiles per wave (M = 147k at 1024
+  // workgroups) a quarter of the waves run one tile longer than the rest.  tools/convbench.py, 1024 -> 512 workgroups:
+  // qkv 128->384 M=147k 36.7 -> 31.2 us, 256->128 M=147k 29.7 -> 22.7, 64->128 M=147k 15.9 -> 12.8, 256->768 M=37k
+  // 33.5 -> 28.2; 768 / 640 / 384 / 256 in between or worse; M = 590k: 36.4 -> 37.0 (stays at 1024).
+  static const int gxcap = [] { const char* e = getenv("DM_GEMM_GX"); return e ? atoi(e) : 0; }();   // developer override
+  int gx = (gxcap > 0 ? gxcap : (p.M >= 262144 ? 1024 : 512)) / gy;
   if (gx < 1) gx = 1;
   if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
   // Workgroups are dealt to the 8 XCDs round-robin by linear id (x + y * gx): with gx a multiple of 8 the gy
