@@ -395,8 +395,15 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restr
   }
 }
 
-int pick_split(int B, int HW) {
-  int ns = 2048 / (B > 0 ? B : 1);
+// Pixel chunks per sample.  Every workgroup pays a fixed prologue (per-channel affine rows, the merge of the partial
+// table, a barrier), so few fat workgroups beat many thin ones: tools/hbmbench.py, B=64, workgroups in total
+// 2048 -> 512 (forward) / 768 (backward): 128ch@48x48 40.8 -> 29.9 us / 65.2 -> 49.3, 256ch@24x24 24.5 -> 19.3 / 36.8 ->
+// 34.6, 64ch@96x96 49.8 -> 44.8 / 79.7 -> 75.3, 256ch@48x48 50.3 -> 44.8 / 87.2 -> 76.5 (backward at 512: 78.8, at 384:
+// 95.8; forward at 256: 47.0).
+int pick_split(int B, int HW, bool bwd) {
+  static const int tf = [] { const char* e = getenv("DM_GN_WGS"); return e ? atoi(e) : 512; }();      // developer overrides
+  static const int tb = [] { const char* e = getenv("DM_GN_WGS_BWD"); return e ? atoi(e) : 768; }();
+  int ns = (bwd ? tb : tf) / (B > 0 ? B : 1);
   if (ns < 1) ns = 1;
   if (ns > 64) ns = 64;
   while (ns > 1 && HW / ns < 32) ns >>= 1;
@@ -406,9 +413,9 @@ int pick_split(int B, int HW) {
 }  // namespace
 
 extern "C" long dm_gn_workspace_bytes(int B, int HW, int C, int G) {
-  const int ns = pick_split(B, HW);
-  const long fwd = (long)B * ns * G * 3 * 4;
-  const long bwd = (long)B * ns * C * 2 * 4 + (long)B * ns * G * 2 * 4;
+  const int nf = pick_split(B, HW, false), nb = pick_split(B, HW, true);
+  const long fwd = (long)B * nf * G * 3 * 4;
+  const long bwd = (long)B * nb * C * 2 * 4 + (long)B * nb * G * 2 * 4;
   return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -419,7 +426,7 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
   DM_REQUIRE(C % 8 == 0 && C <= MAX_C && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0);
   DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && ldy % 8 == 0);
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G));
-  const int ns = pick_split(B, HW);
+  const int ns = pick_split(B, HW, false);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (float*)workspace, HW, C, G, ns);
@@ -437,7 +444,7 @@ extern "C" int dm_gn_prepare(const void* x, long ldx, const float* chan_add, con
   DM_REQUIRE(C % 8 == 0 && C <= MAX_C && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0);
   DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0);
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G));
-  const int ns = pick_split(B, HW);
+  const int ns = pick_split(B, HW, false);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (float*)workspace, HW, C, G, ns);
@@ -457,7 +464,7 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   DM_REQUIRE(C % 8 == 0 && G > 0 && G <= 64 && C % G == 0 && (C / G) % 8 == 0 && C <= MAX_C);
   DM_REQUIRE(256 % (C / 8) == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!add_in || ldadd % 8 == 0));
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G) && drop_p >= 0.f && drop_p < 1.f);
-  const int ns = pick_split(B, HW);
+  const int ns = pick_split(B, HW, true);
   float* ws = (float*)workspace;
   float* wsg = ws + (long)B * ns * C * 2;  // (split, group) partials behind the (split, channel) ones
   hipStream_t st = (hipStream_t)stream;
