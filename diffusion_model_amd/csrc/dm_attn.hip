@@ -654,16 +654,16 @@ __global__ __launch_bounds__(256, DT == 1 ? 4 : 3) void attn_bwd_q_kernel(const 
 
 // ---------------------------------------------------------------- fused backward (head dim 16, 2304 keys per head)
 // attn_bwd_kv_kernel and attn_bwd_q_kernel each recompute the probabilities (exp2, dropout compare / selects): with
-// head dim 16 that VALU work IS the run time of both.  This kernel computes them once.  A workgroup of 8 waves owns
-// HALF the keys of one (batch, head): every wave keeps 9 key tiles (144 keys) resident in registers -- the scaled
+// head dim 16 that VALU work IS the run time of both.  This kernel computes them once.  A workgroup of NW waves (4 as
+// launched) owns a SLICE of the keys of one (batch, head) -- a quarter: every wave keeps 9 key tiles (144 keys) resident in registers -- the scaled
 // hi/lo key fragment for the score MFMA, V^T for dP, K^T for dQ, and the dK^T / dV^T accumulators -- and the workgroup
 // sweeps all queries in blocks of 64 (staged as in attn_bwd_kv_kernel).  Per (16 queries x 16 keys):
 //   S, dP (MFMA) -> P, dS (VALU, once) -> dV^T += dO^T P, dK^T += Q^T dS  (P, dS are already B operands), and
 //   dQ^T += K^T dS^T, whose B operand is the TRANSPOSE of the tile: 8 bytes per lane through a per-wave LDS tile
 //   and one ds_read_b64_tr_b16 back.
-// The dQ^T partial of a wave covers its 144 keys; the 8 waves' partials are summed in wave order through LDS once per
-// 64-query block, and the two workgroups of a (batch, head) leave two fp32 partial arrays that attn_dq_merge_kernel
-// adds (fixed order everywhere: bit-reproducible).  All 16x16x16 MFMAs except the score (hi/lo split in k-slots 16-31).
+// The dQ^T partial of a wave covers its 144 keys; the waves' partials are summed in wave order through LDS once per
+// 64-query block, and the workgroups of a (batch, head) -- one per key split -- leave one fp32 partial array each, which
+// attn_dq_merge_kernel adds in split order (fixed order everywhere: bit-reproducible).  All 16x16x16 MFMAs except the score (hi/lo split in k-slots 16-31).
 constexpr int FB_NK = 2304;                    // keys per head this kernel family is built for
 
 __device__ __forceinline__ s16x4 tr16(const char* a) {
@@ -682,7 +682,7 @@ __device__ __forceinline__ s16x4 pack4(const float (&v)[4]) {
 // NW waves per workgroup, FB_KT key tiles (16 keys) per wave: a workgroup owns NW * FB_KT * 16 keys, and
 // FB_NK / that many workgroups (key splits) share one (batch, head).
 template <bool DROP, int NW, int FB_KT>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(const AttnParams p, float* __restrict__ dq_part) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_fused_kernel(const AttnParams p, float* __restrict__ dq_part) {
   constexpr int DT = 1;
   constexpr int FB_KEYS = NW * FB_KT * 16;
   [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);
@@ -1439,7 +1439,7 @@ bool fused_bwd_enabled() {   // DM_ATTN_BWD_FUSED=0: the two-kernel backward, fo
 }  // namespace
 
 extern "C" long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd) {
-  if (hd == 16 && Nk == FB_NK && Nq % 64 == 0) return (long)2 * B * heads * Nq * 16 * 4;   // two key splits
+  if (hd == 16 && Nk == FB_NK && Nq % 64 == 0) return (long)4 * B * heads * Nq * 16 * 4;   // four key splits
   return 0;
 }
 
@@ -1561,9 +1561,14 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     // 8 waves x 9 key tiles, two key splits.  Measured against it (B=64, dropout 0.1): 12 waves x 4 tiles x 3 splits
     // (168 VGPRs, 3 waves per SIMD) 1162 us and 16 x 3 x 3 (128 VGPRs) 1166 us against 1050 us -- the per-query-tile
     // fixed work and the third dQ partial cost more than the extra waves hide
-    const int rc2 = p.thresh ? launch_fused<true, 8, 9>(p, part, st) : launch_fused<false, 8, 9>(p, part, st);
+    // 4 waves x 9 key tiles, four key splits: a workgroup takes HALF a CU (4 waves x 256 VGPRs), so a convolution
+    // workgroup of the main stream can sit beside it and the VALU-bound attention waves share SIMDs with MFMA-bound
+    // ones.  Against 8 waves x 9 tiles x two splits (a whole CU per workgroup): alone 1011 vs 1058 us (B=64, dropout 0.1),
+    // in the training step 15.10 vs 15.37 ms.  (12 x 4 x 3 and 16 x 3 x 3: 1162 / 1166 us alone.)
+    constexpr int NWF = 4, KTF = 9;
+    const int rc2 = p.thresh ? launch_fused<true, NWF, KTF>(p, part, st) : launch_fused<false, NWF, KTF>(p, part, st);
     if (rc2 != DM_OK) return rc2;
-    const int nsplit = FB_NK / (8 * 9 * 16);
+    const int nsplit = FB_NK / (NWF * KTF * 16);
     long nb = ((long)p.B * p.H * p.Nq * 4 + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(attn_dq_merge_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, (const float*)part,
