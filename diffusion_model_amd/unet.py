@@ -641,6 +641,10 @@ ELIDE_DEAD_ATTENTION = [os.environ.get("DM_ELIDE_DEAD_ATTENTION", "0") == "1"]
 # the attention call that yields the log-sum-exp -- is enqueued on an auxiliary HIP stream, where its VALU-bound
 # kernels run beside the MFMA-bound convolutions of the main chain.  The main stream joins it at the end of the forward.
 OVERLAP_DEAD_ATTENTION = [os.environ.get("DM_OVERLAP_DEAD_ATTENTION", "1") != "0"]
+# ... also in the layers that have a cross-attention block but no self-attention block (L1 / L4 of the STL10 network):
+# there the auxiliary stream takes to_q, to_k, the log-sum-exp and, in the backward, the whole cross-attention backward
+# (DM_OVERLAP_CROSS_ONLY=0: only layers with a self-attention block are scheduled this way).
+OVERLAP_CROSS_ONLY = [os.environ.get("DM_OVERLAP_CROSS_ONLY", "1") != "0"]
 KEEP_DEAD_DX = [False]   # tests: keep the (zero) input gradient of the overlapped backward branch in UnetLayer._dead_dx
 
 
@@ -679,7 +683,7 @@ class UnetLayer(HipModule):
             if has_a and self.attention.training and self.attention.dropout_prob > 0:
                 next(_SEED)  # keep the dropout seed sequence of the un-elided network
             xo, s_c = self.cross_attention._fwd(r, ctx, res=r, out=dst, elide=True)
-        elif has_a and has_c and OVERLAP_DEAD_ATTENTION[0] and ctx.shape[1] == 1:
+        elif has_c and OVERLAP_DEAD_ATTENTION[0] and ctx.shape[1] == 1 and (has_a or OVERLAP_CROSS_ONLY[0]):
             xo, s_a, s_c = self._fwd_attn_overlapped(r, ctx, dst)
         elif has_a and has_c:
             xa, s_a = self.attention._fwd(r)
@@ -706,16 +710,20 @@ class UnetLayer(HipModule):
         main stream computes exactly that and goes on; self-attention, to_q, to_k and the attention call that returns
         the log-sum-exp run on the auxiliary stream (same kernels, same dropout seeds, same saved tensors as the
         single-stream order)."""
-        ca, at = self.cross_attention, self.attention
-        B, H, W, C = r.shape
+        ca, at = self.cross_attention, getattr(self, "attention", None)   # (no self-attention block: only to_q / to_k
+        B, H, W, C = r.shape                                              #  and the log-sum-exp go to the other stream)
         N = H * W
-        p_a = at.dropout_prob if at.training else 0.0
+        p_a = at.dropout_prob if (at is not None and at.training) else 0.0
         seed_a = next(_SEED) if p_a > 0 else 0          # the single-stream order draws attention's seed first
         p_c = ca.dropout_prob if ca.training else 0.0
         seed_c = next(_SEED) if p_c > 0 else 0
         vc = K.gemm(ctx, PW.of(ca.to_v).fwd, C)
         with K.on_aux(r.device):
-            xa, s_a = at._fwd(r, seed=seed_a)
+            K.hold_for_aux(r.device, r, vc)
+            s_a = None
+            xa = r
+            if at is not None:
+                xa, s_a = at._fwd(r, seed=seed_a)
             tok = xa.view(B, N, C)
             q = K.gemm(tok, PW.of(ca.to_q).fwd, C)
             kc = K.gemm(ctx, PW.of(ca.to_k).fwd, C)
@@ -740,8 +748,8 @@ class UnetLayer(HipModule):
             if hasattr(self, "attention"):  # zero gradients, exactly: leave the accumulators untouched
                 g.of(self.attention.linear_qkv.weight), g.of(self.attention.linear_out.weight)
             dr = dxo  # d(xo)/d(r) is the residual branch alone
-        elif (s_a is not None and s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1
-              and g.dctx is None):   # (a context gradient is accumulated across layers: keep that on one stream)
+        elif (s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1
+              and (s_a is not None or OVERLAP_CROSS_ONLY[0]) and g.dctx is None):   # (a context gradient is accumulated across layers: keep that on one stream)
             # One context token: d(cross_attention)/d(its query input) is exactly 0 (dq = 0 out of a softmax over one
             # key), so the gradient that comes back through attention(r) is an exact zero and dr = dxo.  Everything
             # still runs -- cross-attention backward (to_out / to_v / to_q / to_k gradients) and the whole self-attention
@@ -750,9 +758,9 @@ class UnetLayer(HipModule):
             with K.on_aux(dxo.device):
                 K.hold_for_aux(dxo.device, dxo)
                 dxa, _ = self.cross_attention._bwd(dxo, s_c, g)
-                self._dead_dx = self.attention._bwd(dxa, s_a, g) if KEEP_DEAD_DX[0] else None
-                if not KEEP_DEAD_DX[0]:
-                    self.attention._bwd(dxa, s_a, g)
+                if s_a is not None:
+                    dxa = self.attention._bwd(dxa, s_a, g)
+                self._dead_dx = dxa if KEEP_DEAD_DX[0] else None
             dr = dxo
         elif s_a is not None and s_c is not None:
             dxa, _ = self.cross_attention._bwd(dxo, s_c, g)

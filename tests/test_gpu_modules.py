@@ -214,13 +214,15 @@ def test_state_dict_is_reference_compatible():
     assert "time_embeddings.embeddings" not in got  # non-persistent buffer (reference unet.py:54)
 
 
-def test_overlapped_attention_backward_is_exact():
+@pytest.mark.parametrize("self_attention", [True, False])
+def test_overlapped_attention_backward_is_exact(self_attention):
     """One context token: UnetLayer._bwd runs the cross-attention and self-attention backward on the auxiliary stream and
     does not add what comes back through attention(r) -- it must be an exact zero, and input / parameter gradients must
     equal the single-stream order's."""
     from diffusion_model_amd import unet as U
     torch.manual_seed(3)
-    layer = U.UnetLayer(False, True, 8, 0.1, 64, 64, 256, num_heads=8, use_cross_attention=True, context_dim=512).to(dev())
+    layer = U.UnetLayer(False, self_attention, 8, 0.1, 64, 64, 256, num_heads=8, use_cross_attention=True,
+                        context_dim=512).to(dev())   # (False: the layers with a cross-attention block only, L1 / L4)
     layer.train()
     B, H = 4, 24
     x = torch.randn(B, H, H, 64, device=dev()).to(torch.bfloat16)
@@ -254,7 +256,10 @@ def test_overlapped_attention_backward_is_exact():
         ref = b[2][n]
         err = float((a[2][n] - ref).abs().max())
         assert err <= 1e-5 * max(1.0, float(ref.abs().max())), (n, err)   # (GroupNorm partial merges use fp32 atomics)
-    for n in ("attention.linear_qkv.weight", "attention.linear_out.weight", "cross_attention.to_q.weight", "cross_attention.to_k.weight"):
+    dead = ("cross_attention.to_q.weight", "cross_attention.to_k.weight")
+    if self_attention:
+        dead += ("attention.linear_qkv.weight", "attention.linear_out.weight")
+    for n in dead:
         assert float(a[2][n].abs().max()) == 0.0, f"{n}: dead parameter with a non-zero gradient"
 
 
