@@ -1052,242 +1052,364 @@ __global__ void attn_small_finish_kernel(const AttnParams p, const float* __rest
 
 
 // ---------------------------------------------------------------- wide heads (hd = 64, 128)
-// The latent-diffusion model's self-attention (utils.py:145-156: 512 and 1024 channels over 8 heads, at most 256
-// tokens at 32x32 latents).  Plain fp32 VALU kernels -- at these sizes the attention is a few percent of a step that
-// the wide convolutions dominate, so they are written for exactness and simplicity, not for the MFMA pipe:
-// thread = (row, eighth of the head): 8 consecutive lanes own one query (or key) row, each hd/8 of its dimensions;
-// dot products combine over the 8 lanes with three shuffles; the other operand's rows are staged 32 at a time in LDS
-// and read as broadcasts.  Same dropout words as the few-token kernels (row = (b*H+h)*Nq + q, column = key).
+// ---------------------------------------------------------------- wide heads (64 / 128) on the MFMA pipe
+// The latent-diffusion model's self-attention (utils.py:145-156: 512 and 1024 channels over 8 heads, 256 and 64 tokens
+// at 32x32 latents).  With head dims this wide a score costs 4*hd = 256..512 MFMA flop, so these kernels are MFMA /
+// LDS-read bound, not VALU bound, and are kept plain: same register-resident P trick as the flash kernels (score tile
+// computed transposed, keys on MFMA rows, so a lane already owns the 8 keys per 32-key step that the second MFMA
+// wants), but the raw q.k accumulator is scaled on the VALU (no hi/lo split), the softmax rescales in every key block,
+// and the keys / values of a (batch, head) are staged KCH rows at a time into one LDS image (no double buffering:
+// at <= 256 keys a workgroup stages once or twice).  Row stride: hd*2 bytes + 32 (hd 64: 160) or + 96 (hd 128: 352) --
+// 10 resp. 22 sixteen-byte units, i.e. +-6 mod 16, which keeps both the ds_read_b128 operand reads and the
+// ds_read_b64_tr_b16 halves bank-conflict free (same argument as RS above).
+// Dropout words: the few-token convention (row word of the query, one 32-bit draw per key pair).
+template <int HD> struct Wide {
+  static constexpr int RSW = HD == 64 ? 160 : 352;   // LDS row stride, bytes
+  static constexpr int KC = HD / 32;                 // 32-wide reduction chunks of a q.k product
+  static constexpr int DT = HD / 16;                 // 16-row tiles of a head-dim-major output
+  static constexpr int KCH = HD == 64 ? 128 : 64;    // rows staged per LDS image
+};
+
+// rows [r0, r0 + nrows) of one (batch, head) slice -> LDS rows 0..nrows-1; rows past n_valid are zero-filled
 template <int HD>
-__device__ __forceinline__ void wide_stage(bf16* sA, const bf16* a, long lda, bf16* sB, const bf16* b, long ldb, long base,
-                                           int r0, int n, int hoff, int tid) {
-  constexpr int PPR = HD / 8;  // 16-byte pieces per row
-  for (int i = tid; i < 32 * PPR; i += 256) {
+__device__ __forceinline__ void wide_stage_rows(char* dst, const bf16* src, long ld, long rowbase, int r0, int nrows,
+                                                int n_valid, int hoff, int tid) {
+  constexpr int PPR = HD / 8, RSW = Wide<HD>::RSW;
+  for (int i = tid; i < nrows * PPR; i += 256) {
     const int r = i / PPR, pc = i % PPR;
-    u32x4 va = {0u, 0u, 0u, 0u}, vb = va;
-    if (r0 + r < n) {
-      va = *reinterpret_cast<const u32x4*>(a + (base + r0 + r) * lda + hoff + pc * 8);
-      vb = *reinterpret_cast<const u32x4*>(b + (base + r0 + r) * ldb + hoff + pc * 8);
-    }
-    *reinterpret_cast<u32x4*>(sA + r * HD + pc * 8) = va;
-    *reinterpret_cast<u32x4*>(sB + r * HD + pc * 8) = vb;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < n_valid) v = *reinterpret_cast<const u32x4*>(src + (rowbase + r0 + r) * ld + hoff + pc * 8);
+    *reinterpret_cast<u32x4*>(dst + r * RSW + pc * 16) = v;
   }
 }
-__device__ __forceinline__ float wide_sum8(float s) {
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-  return s;
-}
-// v[u] = this lane's partial sum for item u (8 items, 8 lanes per row): returns the full sum of item `part`
-// (7 shuffles for 8 items instead of 3 per item).
-__device__ __forceinline__ float wide_transpose_sum8(const float (&v)[8], int part) {
-  float w[4], x[2];
-  const bool h4 = part & 4, h2 = part & 2, h1 = part & 1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (h4 ? v[4 + i] : v[i]) + __shfl_xor(h4 ? v[i] : v[4 + i], 4, 64);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) x[i] = (h2 ? w[2 + i] : w[i]) + __shfl_xor(h2 ? w[i] : w[2 + i], 2, 64);
-  return (h1 ? x[1] : x[0]) + __shfl_xor(h1 ? x[0] : x[1], 1, 64);
-}
-__device__ __forceinline__ float wide_max8(float s) {
-  s = fmaxf(s, __shfl_xor(s, 1, 64)); s = fmaxf(s, __shfl_xor(s, 2, 64)); s = fmaxf(s, __shfl_xor(s, 4, 64));
-  return s;
-}
+// fragment of row `tok` straight from global: head-dim elements [kc*32 + 8g, +8) for every reduction chunk kc
 template <int HD>
-__device__ __forceinline__ void wide_load_row(const bf16* base, bool ok, float scale, float (&f)[HD / 8]) {
+__device__ __forceinline__ void wide_row_frags(const bf16* base, long ld, long tok, bool ok, int hoff, int g,
+                                               bf16x8 (&f)[HD / 32]) {
 #pragma unroll
-  for (int d0 = 0; d0 < HD / 8; d0 += 8) {
-    bf16x8 v = {};
-    if (ok) v = *reinterpret_cast<const bf16x8*>(base + d0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[d0 + j] = (float)v[j] * scale;
-  }
+  for (int kc = 0; kc < HD / 32; ++kc)
+    f[kc] = ok ? *reinterpret_cast<const bf16x8*>(base + tok * ld + hoff + kc * 32 + 8 * g) : zero8();
 }
-template <int HD>
-__device__ __forceinline__ void wide_store_row(bf16* base, const float (&f)[HD / 8], float scale) {
-#pragma unroll
-  for (int d0 = 0; d0 < HD / 8; d0 += 8) {
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (bf16)(f[d0 + j] * scale);
-    *reinterpret_cast<bf16x8*>(base + d0) = v;
-  }
+__device__ __forceinline__ float wide_zf(uint32_t rs, int key, uint32_t thresh, float inv_keep) {
+  return dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, thresh) ? inv_keep : 0.f;
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const AttnParams p) {
-  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
-  constexpr int DPT = HD / 8;
-  __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
-  __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
-  const int tid = threadIdx.x, ql = tid >> 3, part = tid & 7;
+// forward: a wave owns QT tiles of 16 queries (queries on the lane axis), the workgroup 64*QT queries
+template <int HD, int QT>
+__global__ __launch_bounds__(256, 2) void attn_wide_fwd_kernel(const AttnParams p) {
+  constexpr int RSW = Wide<HD>::RSW, KC = Wide<HD>::KC, DT = Wide<HD>::DT, KCH = Wide<HD>::KCH;
+  const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
+  __shared__ __attribute__((aligned(16))) char sK[KCH * RSW];
+  __shared__ __attribute__((aligned(16))) char sV[KCH * RSW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int qq = li >> 2, pp = li & 3;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
-  const int q = blockIdx.x * 32 + ql;
-  const bool q_ok = q < p.Nq;
-  float qf[DPT], acc[DPT];
-  wide_load_row<HD>(p.q + ((long)b * p.Nq + q) * p.ldq + hoff + part * DPT, q_ok, p.scale, qf);
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[QT][KC];
+  int qi[QT];
+  uint32_t rs[QT];
+  float m[QT], l[QT];
+  f32x4 acc[DT][QT];
 #pragma unroll
-  for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
-  float m = NEG, l = 0.f;  // finite sentinel: the library is built with -ffast-math (no infinities)
-  const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q));
-  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
-    __syncthreads();
-    wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
-    __syncthreads();
-    const int kn = min(32, p.Nk - k0);
-    // eight keys per round: every lane adds its slice of the eight dot products, a transposing reduction leaves lane
-    // `part` with the score of key j0 + part, so exp / dropout run once per key (not once per lane), and the eight
-    // probabilities go back out as broadcasts for the P.V update.  l is kept as per-lane partial sums.
-    for (int j0 = 0; j0 < kn; j0 += 8) {
-      float ps[8];
+  for (int qt = 0; qt < QT; ++qt) {
+    qi[qt] = q0 + qt * 16 + li;
+    wide_row_frags<HD>(p.q, p.ldq, qbase + qi[qt], qi[qt] < p.Nq, hoff, g, qf[qt]);
+    rs[qt] = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi[qt]));
+    m[qt] = NEG;
+    l[qt] = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
-        float t = 0.f;
-#pragma unroll
-        for (int d = 0; d < DPT; ++d) t += qf[d] * (float)kr[d];
-        ps[u] = t;
-      }
-      const int key = k0 + j0 + part;
-      const float st = wide_transpose_sum8(ps, part);   // every lane takes part in the shuffles
-      const float sc = key < p.Nk ? st : NEG;
-      const float mn = fmaxf(m, wide_max8(sc));
-      const float alpha = __expf(m - mn), pj = __expf(sc - mn);
-      l = l * alpha + pj;
-      float pd = pj;
-      if (p.thresh) pd = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? pj * p.inv_keep : 0.f;
-#pragma unroll
-      for (int d = 0; d < DPT; ++d) acc[d] *= alpha;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float pu = __shfl(pd, (tid & 56) | u, 64);
-        const bf16* vr = sV + (j0 + u) * HD + part * DPT;
-#pragma unroll
-        for (int d = 0; d < DPT; ++d) acc[d] += pu * (float)vr[d];
-      }
-      m = mn;
-    }
+    for (int dt = 0; dt < DT; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  l = wide_sum8(l);
-  if (q_ok) {
-    wide_store_row<HD>(p.o + ((long)b * p.Nq + q) * p.ldo + hoff + part * DPT, acc, 1.f / l);
-    if (part == 0) p.lse[(long)bh * p.Nq + q] = m + __logf(l);
-  }
-}
-
-// dQ: the forward's mapping; P is rebuilt from the saved log-sum-exp.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_wide_bwd_q_kernel(const AttnParams p) {
-  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
-  constexpr int DPT = HD / 8;
-  __shared__ __attribute__((aligned(16))) bf16 sK[32 * HD];
-  __shared__ __attribute__((aligned(16))) bf16 sV[32 * HD];
-  const int tid = threadIdx.x, ql = tid >> 3, part = tid & 7;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
-  const int q = blockIdx.x * 32 + ql;
-  const bool q_ok = q < p.Nq;
-  float qf[DPT], df[DPT], acc[DPT];
-  wide_load_row<HD>(p.q + ((long)b * p.Nq + q) * p.ldq + hoff + part * DPT, q_ok, p.scale, qf);
-  wide_load_row<HD>(p.d_o + ((long)b * p.Nq + q) * p.lddo + hoff + part * DPT, q_ok, 1.f, df);
-#pragma unroll
-  for (int d = 0; d < DPT; ++d) acc[d] = 0.f;
-  const float L = q_ok ? p.lse[(long)bh * p.Nq + q] : 0.f;
-  const float dl = q_ok ? p.delta[(long)bh * p.Nq + q] : 0.f;
-  const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q));
-  for (int k0 = 0; k0 < p.Nk; k0 += 32) {
+  for (int k0 = 0; k0 < p.Nk; k0 += KCH) {
+    const int nrows = min(KCH, (p.Nk - k0 + 63) & ~63);
     __syncthreads();
-    wide_stage<HD>(sK, p.k, p.ldk, sV, p.v, p.ldv, (long)b * p.Nk, k0, p.Nk, hoff, tid);
+    wide_stage_rows<HD>(sK, p.k, p.ldk, kbase, k0, nrows, p.Nk, hoff, tid);
+    wide_stage_rows<HD>(sV, p.v, p.ldv, kbase, k0, nrows, p.Nk, hoff, tid);
     __syncthreads();
-    const int kn = min(32, p.Nk - k0);
-    for (int j0 = 0; j0 < kn; j0 += 8) {  // eight keys per round, as in the forward
-      float ps[8], pp[8];
+    for (int kb = 0; kb < nrows; kb += 64) {
+      f32x4 st[4][QT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
-        const bf16* vr = sV + (j0 + u) * HD + part * DPT;
-        float t = 0.f, t2 = 0.f;
+      for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int d = 0; d < DPT; ++d) { t += qf[d] * (float)kr[d]; t2 += df[d] * (float)vr[d]; }
-        ps[u] = t; pp[u] = t2;
+        for (int qt = 0; qt < QT; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb + kt * 16 + li) * RSW + kc * 64 + g * 16);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kc], st[kt][qt], 0, 0, 0);
+        }
       }
-      const int key = k0 + j0 + part;
-      const float sc = wide_transpose_sum8(ps, part), dp = wide_transpose_sum8(pp, part);
-      const float pj = key < p.Nk ? __expf(sc - L) : 0.f;
-      float zf = 1.f;
-      if (p.thresh) zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
-      const float ds = pj * (zf * dp - dl);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float du = __shfl(ds, (tid & 56) | u, 64);
-        const bf16* kr = sK + (j0 + u) * HD + part * DPT;
+      for (int qt = 0; qt < QT; ++qt) {
+        float t = NEG;
 #pragma unroll
-        for (int d = 0; d < DPT; ++d) acc[d] += du * (float)kr[d];
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kb + kt * 16 + 4 * g + r;
+            const float s = key < p.Nk ? st[kt][qt][r] * c : NEG;
+            st[kt][qt][r] = s;
+            t = fmaxf(t, s);
+          }
+        t = fmaxf(t, __shfl_xor(t, 16, 64));
+        t = fmaxf(t, __shfl_xor(t, 32, 64));
+        const float mn = fmaxf(m[qt], t);
+        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);   // first block: m = NEG -> 0 (and l = acc = 0)
+        m[qt] = mn;
+        l[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt][qt] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kb + kt * 16 + 4 * g + r;
+            // the row sum takes the bf16-rounded, undropped probability: what the second MFMA multiplies
+            float pj = (float)(bf16)__builtin_amdgcn_exp2f(st[kt][qt][r] - mn);
+            if (key >= p.Nk) pj = 0.f;
+            l[qt] += pj;
+            if (p.thresh && wide_zf(rs[qt], key, p.thresh, 1.f) == 0.f) pj = 0.f;
+            st[kt][qt][r] = pj;
+          }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pb[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) pb[qt] = pack8(st[2 * ks][qt], st[2 * ks + 1][qt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* a0 = sV + (kb + ks * 32 + 4 * g + qq) * RSW + dt * 32 + pp * 8;
+          const bf16x8 vT = tr_pair(a0, a0 + 16 * RSW);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vT, pb[qt], acc[dt][qt], 0, 0, 0);
+        }
       }
     }
   }
-  if (q_ok) wide_store_row<HD>(p.dq + ((long)b * p.Nq + q) * p.lddq + hoff + part * DPT, acc, p.scale);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    if (qi[qt] < p.Nq) {
+      const float inv = (p.thresh ? p.inv_keep : 1.f) / lt;
+      if (g == 0 && p.lse) p.lse[(long)bh * p.Nq + qi[qt]] = (m[qt] + log2f(lt)) * LN2;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[dt][qt][r] * inv);
+        *reinterpret_cast<bf16x4*>(p.o + (qbase + qi[qt]) * p.ldo + hoff + dt * 16 + 4 * g) = o;
+      }
+    }
+  }
 }
 
-// dK, dV: thread = (key, eighth of the head); queries and their dO rows staged 32 at a time.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_wide_bwd_kv_kernel(const AttnParams p) {
-  [[maybe_unused]] const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
-  constexpr int DPT = HD / 8;
-  __shared__ __attribute__((aligned(16))) bf16 sQ[32 * HD];
-  __shared__ __attribute__((aligned(16))) bf16 sD[32 * HD];
-  __shared__ float sL[32], sDl[32];
-  const int tid = threadIdx.x, kl = tid >> 3, part = tid & 7;
+// dQ: the forward's mapping; P is rebuilt from the saved log-sum-exp, dP^T = V dO^T comes from a second MFMA against
+// the staged values, and dQ^T = K^T dS^T reads the staged keys through the transposing LDS read.
+template <int HD, int QT>
+__global__ __launch_bounds__(256, 2) void attn_wide_bwd_q_kernel(const AttnParams p) {
+  constexpr int RSW = Wide<HD>::RSW, KC = Wide<HD>::KC, DT = Wide<HD>::DT, KCH = Wide<HD>::KCH;
+  const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
+  __shared__ __attribute__((aligned(16))) char sK[KCH * RSW];
+  __shared__ __attribute__((aligned(16))) char sV[KCH * RSW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int qq = li >> 2, pp = li & 3;
   const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
-  const int key = blockIdx.x * 32 + kl;
-  const bool k_ok = key < p.Nk;
-  float kf[DPT], vf[DPT], dk[DPT], dv[DPT];
-  wide_load_row<HD>(p.k + ((long)b * p.Nk + key) * p.ldk + hoff + part * DPT, k_ok, p.scale, kf);
-  wide_load_row<HD>(p.v + ((long)b * p.Nk + key) * p.ldv + hoff + part * DPT, k_ok, 1.f, vf);
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const float c = p.scale * LOG2E;
+  bf16x8 qf[QT][KC], df[QT][KC];
+  int qi[QT];
+  uint32_t rs[QT];
+  float L2[QT], dl[QT];
+  f32x4 acc[DT][QT];
 #pragma unroll
-  for (int d = 0; d < DPT; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-  for (int q0 = 0; q0 < p.Nq; q0 += 32) {
+  for (int qt = 0; qt < QT; ++qt) {
+    qi[qt] = q0 + qt * 16 + li;
+    const bool ok = qi[qt] < p.Nq;
+    wide_row_frags<HD>(p.q, p.ldq, qbase + qi[qt], ok, hoff, g, qf[qt]);
+    wide_row_frags<HD>(p.d_o, p.lddo, qbase + qi[qt], ok, hoff, g, df[qt]);
+    rs[qt] = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi[qt]));
+    L2[qt] = ok ? p.lse[(long)bh * p.Nq + qi[qt]] * LOG2E : 0.f;
+    dl[qt] = ok ? p.delta[(long)bh * p.Nq + qi[qt]] : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int k0 = 0; k0 < p.Nk; k0 += KCH) {
+    const int nrows = min(KCH, (p.Nk - k0 + 63) & ~63);
     __syncthreads();
-    wide_stage<HD>(sQ, p.q, p.ldq, sD, p.d_o, p.lddo, (long)b * p.Nq, q0, p.Nq, hoff, tid);
-    if (tid < 32) {
-      const bool ok = q0 + tid < p.Nq;
-      sL[tid] = ok ? p.lse[(long)bh * p.Nq + q0 + tid] : 0.f;
+    wide_stage_rows<HD>(sK, p.k, p.ldk, kbase, k0, nrows, p.Nk, hoff, tid);
+    wide_stage_rows<HD>(sV, p.v, p.ldv, kbase, k0, nrows, p.Nk, hoff, tid);
+    __syncthreads();
+    for (int kb = 0; kb < nrows; kb += 64) {
+      f32x4 st[4][QT], dp[4][QT];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) { st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = st[kt][qt]; }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const int off = (kb + kt * 16 + li) * RSW + kc * 64 + g * 16;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kc], st[kt][qt], 0, 0, 0);
+            dp[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[qt][kc], dp[kt][qt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kb + kt * 16 + 4 * g + r;
+            const float pj = key < p.Nk ? __builtin_amdgcn_exp2f(st[kt][qt][r] * c - L2[qt]) : 0.f;
+            const float zf = p.thresh ? wide_zf(rs[qt], key, p.thresh, p.inv_keep) : 1.f;
+            st[kt][qt][r] = pj * (zf * dp[kt][qt][r] - dl[qt]);
+          }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 sb[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sb[qt] = pack8(st[2 * ks][qt], st[2 * ks + 1][qt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* a0 = sK + (kb + ks * 32 + 4 * g + qq) * RSW + dt * 32 + pp * 8;
+          const bf16x8 kT = tr_pair(a0, a0 + 16 * RSW);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+            acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sb[qt], acc[dt][qt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+    if (qi[qt] < p.Nq) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)(acc[dt][qt][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(p.dq + (qbase + qi[qt]) * p.lddq + hoff + dt * 16 + 4 * g) = o;
+      }
+    }
+}
+
+// dK, dV: keys on the lane axis (a wave owns KT tiles of 16 keys, their k / v fragments resident in registers), the
+// queries and their dO rows staged 64 at a time; S = Q K^T and dP = dO V^T read the staged rows as MFMA A operands,
+// dV^T = dO^T P and dK^T = Q^T dS read them again through the transposing LDS read.
+template <int HD, int KT>
+__global__ __launch_bounds__(256, 2) void attn_wide_bwd_kv_kernel(const AttnParams p) {
+  constexpr int RSW = Wide<HD>::RSW, KC = Wide<HD>::KC, DT = Wide<HD>::DT;
+  const uint32_t seed_eff = dm_eff_seed(p.seed, p.seed_ctr);  // host seed + device counter (graph replay)
+  __shared__ __attribute__((aligned(16))) char sQ[64 * RSW];
+  __shared__ __attribute__((aligned(16))) char sD[64 * RSW];
+  __shared__ float sL[64], sDl[64];
+  __shared__ uint32_t sRS[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int qq = li >> 2, pp = li & 3;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hoff = h * HD;
+  const long qbase = (long)b * p.Nq, kbase = (long)b * p.Nk;
+  const int kk0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+  const float c = p.scale * LOG2E;
+  bf16x8 kf[KT][KC], vf[KT][KC];
+  int key[KT];
+  f32x4 dk[DT][KT], dv[DT][KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    key[kt] = kk0 + kt * 16 + li;
+    wide_row_frags<HD>(p.k, p.ldk, kbase + key[kt], key[kt] < p.Nk, hoff, g, kf[kt]);
+    wide_row_frags<HD>(p.v, p.ldv, kbase + key[kt], key[kt] < p.Nk, hoff, g, vf[kt]);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+  }
+  for (int q0 = 0; q0 < p.Nq; q0 += 64) {
+    __syncthreads();
+    wide_stage_rows<HD>(sQ, p.q, p.ldq, qbase, q0, 64, p.Nq, hoff, tid);
+    wide_stage_rows<HD>(sD, p.d_o, p.lddo, qbase, q0, 64, p.Nq, hoff, tid);
+    if (tid < 64) {
+      const bool ok = q0 + tid < p.Nq;   // rows past the end: q = dO = 0 and delta = 0, so dS = P * (0 - 0) = 0 and P * dO = 0
+      sL[tid] = ok ? p.lse[(long)bh * p.Nq + q0 + tid] * LOG2E : 0.f;
       sDl[tid] = ok ? p.delta[(long)bh * p.Nq + q0 + tid] : 0.f;
+      sRS[tid] = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + q0 + tid));
     }
     __syncthreads();
-    const int qn = min(32, p.Nq - q0);
-    for (int i0 = 0; i0 < qn; i0 += 8) {  // eight queries per round: lane `part` finishes query i0 + part
-      float ps[8], pp[8];
+    f32x4 st[4][KT], dp[4][KT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bf16* qr = sQ + (i0 + u) * HD + part * DPT;
-        const bf16* dr = sD + (i0 + u) * HD + part * DPT;
-        float t = 0.f, t2 = 0.f;
+    for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
-        for (int d = 0; d < DPT; ++d) { t += kf[d] * (float)qr[d]; t2 += vf[d] * (float)dr[d]; }
-        ps[u] = t; pp[u] = t2;
+      for (int kt = 0; kt < KT; ++kt) { st[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = st[qt][kt]; }
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const int off = (qt * 16 + li) * RSW + kc * 64 + g * 16;
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + off);
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(sD + off);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][kc], st[qt][kt], 0, 0, 0);
+          dp[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][kc], dp[qt][kt], 0, 0, 0);
+        }
       }
-      const int qi = q0 + i0 + part;
-      const float sc = wide_transpose_sum8(ps, part), dp = wide_transpose_sum8(pp, part);
-      const float pj = qi < p.Nq ? __expf(sc - sL[i0 + part]) : 0.f;
-      float zf = 1.f;
-      if (p.thresh) {
-        const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)(bh * p.Nq + qi));
-        zf = dm_keep16(dm_drop_bits(rs, (uint32_t)key >> 1), (uint32_t)key, p.thresh) ? p.inv_keep : 0.f;
+    }
+    // st -> dS, dp -> dropped P (both in place)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qt * 16 + 4 * g + r;
+        const float L = sL[ql], Dl = sDl[ql];
+        const uint32_t rsq = sRS[ql];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const float pj = key[kt] < p.Nk ? __builtin_amdgcn_exp2f(st[qt][kt][r] * c - L) : 0.f;
+          const float zf = p.thresh ? wide_zf(rsq, key[kt], p.thresh, p.inv_keep) : 1.f;
+          st[qt][kt][r] = pj * (zf * dp[qt][kt][r] - Dl);
+          dp[qt][kt][r] = pj * zf;
+        }
       }
-      const float ds = pj * (zf * dp - sDl[i0 + part]), pz = pj * zf;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float du = __shfl(ds, (tid & 56) | u, 64), zu = __shfl(pz, (tid & 56) | u, 64);
-        const bf16* qr = sQ + (i0 + u) * HD + part * DPT;
-        const bf16* dr = sD + (i0 + u) * HD + part * DPT;
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 sb[KT], pb[KT];
 #pragma unroll
-        for (int d = 0; d < DPT; ++d) { dk[d] += du * (float)qr[d]; dv[d] += zu * (float)dr[d]; }
+      for (int kt = 0; kt < KT; ++kt) {
+        sb[kt] = pack8(st[2 * ks][kt], st[2 * ks + 1][kt]);
+        pb[kt] = pack8(dp[2 * ks][kt], dp[2 * ks + 1][kt]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int off = (ks * 32 + 4 * g + qq) * RSW + dt * 32 + pp * 8;
+        const bf16x8 qT = tr_pair(sQ + off, sQ + off + 16 * RSW);
+        const bf16x8 dT = tr_pair(sD + off, sD + off + 16 * RSW);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sb[kt], dk[dt][kt], 0, 0, 0);
+          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pb[kt], dv[dt][kt], 0, 0, 0);
+        }
       }
     }
   }
-  if (k_ok) {
-    wide_store_row<HD>(p.dk + ((long)b * p.Nk + key) * p.lddk + hoff + part * DPT, dk, p.scale);
-    wide_store_row<HD>(p.dv + ((long)b * p.Nk + key) * p.lddv + hoff + part * DPT, dv, 1.f);
-  }
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+    if (key[kt] < p.Nk) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 ok_, ov_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok_[r] = (bf16)(dk[dt][kt][r] * p.scale); ov_[r] = (bf16)dv[dt][kt][r]; }
+        *reinterpret_cast<bf16x4*>(p.dk + (kbase + key[kt]) * p.lddk + hoff + dt * 16 + 4 * g) = ok_;
+        *reinterpret_cast<bf16x4*>(p.dv + (kbase + key[kt]) * p.lddv + hoff + dt * 16 + 4 * g) = ov_;
+      }
+    }
 }
 
 // ---------------------------------------------------------------- one context token (the CLIP table)
@@ -1468,12 +1590,14 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
-  if (p.hd >= 64) {  // wide heads (latent-model widths): fp32 VALU kernels
-    DM_REQUIRE((p.ldo & 7) == 0);
-    const dim3 g((p.Nq + 31) / 32, p.B * p.H);
-    dm_set_variant("attn_wide_fwd");
-    if (p.hd == 64) hipLaunchKernelGGL(attn_wide_fwd_kernel<64>, g, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_wide_fwd_kernel<128>, g, dim3(256), 0, (hipStream_t)stream, p);
+  if (p.hd >= 64) {  // wide heads (latent-model widths): MFMA kernels, two query tiles per wave when there are enough queries
+    const bool two = p.Nq >= 128;
+    const dim3 g((p.Nq + (two ? 127 : 63)) / (two ? 128 : 64), p.B * p.H);
+    dm_set_variant(two ? "attn_wide_mfma_fwd<QT=2>" : "attn_wide_mfma_fwd<QT=1>");
+#define DM_WF(HD, QT) hipLaunchKernelGGL((attn_wide_fwd_kernel<HD, QT>), g, dim3(256), 0, (hipStream_t)stream, p)
+    if (p.hd == 64) { if (two) DM_WF(64, 2); else DM_WF(64, 1); }
+    else { if (two) DM_WF(128, 2); else DM_WF(128, 1); }
+#undef DM_WF
     DM_LAUNCH_CHECK();
     return DM_OK;
   }
@@ -1538,16 +1662,21 @@ extern "C" int dm_attn_bwd(const dm_attn_args* a, dm_stream_t stream) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, st, p);
   }
   DM_LAUNCH_CHECK();
-  if (p.hd >= 64) {
-    DM_REQUIRE((p.lddq & 7) == 0 && (p.lddk & 7) == 0 && (p.lddv & 7) == 0);
-    const dim3 gk((p.Nk + 31) / 32, p.B * p.H), gqw((p.Nq + 31) / 32, p.B * p.H);
-    dm_set_variant("attn_wide_bwd");
+  if (p.hd >= 64) {  // wide heads: MFMA kernels (two key tiles per wave at head dim 64 when there are enough keys)
+    const bool twoq = p.hd == 64 && p.Nq >= 128, twok = p.hd == 64 && p.Nk >= 128;
+    const dim3 gk((p.Nk + (twok ? 127 : 63)) / (twok ? 128 : 64), p.B * p.H);
+    const dim3 gqw((p.Nq + (twoq ? 127 : 63)) / (twoq ? 128 : 64), p.B * p.H);
+    dm_set_variant("attn_wide_mfma_bwd");
     if (p.hd == 64) {
-      hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<64>, gk, dim3(256), 0, st, p);
-      hipLaunchKernelGGL(attn_wide_bwd_q_kernel<64>, gqw, dim3(256), 0, st, p);
+      if (twok) hipLaunchKernelGGL((attn_wide_bwd_kv_kernel<64, 2>), gk, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_wide_bwd_kv_kernel<64, 1>), gk, dim3(256), 0, st, p);
+      DM_LAUNCH_CHECK();
+      if (twoq) hipLaunchKernelGGL((attn_wide_bwd_q_kernel<64, 2>), gqw, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_wide_bwd_q_kernel<64, 1>), gqw, dim3(256), 0, st, p);
     } else {
-      hipLaunchKernelGGL(attn_wide_bwd_kv_kernel<128>, gk, dim3(256), 0, st, p);
-      hipLaunchKernelGGL(attn_wide_bwd_q_kernel<128>, gqw, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_wide_bwd_kv_kernel<128, 1>), gk, dim3(256), 0, st, p);
+      DM_LAUNCH_CHECK();
+      hipLaunchKernelGGL((attn_wide_bwd_q_kernel<128, 1>), gqw, dim3(256), 0, st, p);   // two query tiles would spill at 256 VGPRs
     }
     DM_LAUNCH_CHECK();
     return DM_OK;

@@ -178,7 +178,7 @@ typedef struct dm_attn_args {
   float* delta;                   /* fp32 scratch (backward): max(B*heads*Nq, 2*B*Nk*heads*hd) floats;
                                      with Nk == 1: 32*B*heads*hd floats (per-block partial sums of dV) */
   int B, heads, Nq, Nk, hd;       /* hd in {8,16,32} (MFMA flash / few-token kernels) or {64,128} (latent-model widths,
-                                     utils.py:145-156: fp32 VALU kernels) */
+                                     utils.py:145-156: MFMA kernels with LDS-staged keys) */
   float scale;                    /* 1/sqrt(hd) */
   float drop_p; unsigned long long drop_seed;
   void* workspace; long ws_bytes; /* backward, optional: dm_attn_bwd_workspace_bytes() bytes of scratch.  With it, the shapes

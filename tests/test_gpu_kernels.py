@@ -232,6 +232,7 @@ def ref_attn(q, k, v, heads):
                                        (2, 300, 16, 256), (1, 100, 17, 64), (3, 2304, 1, 128), (2, 130, 1, 256),
                                        # head sizes 64 / 128: the latent model's widths (utils.py:145-156)
                                        (2, 256, 256, 512), (2, 64, 64, 1024), (1, 100, 37, 512), (2, 45, 3, 1024),
+                                       (1, 200, 150, 1024), (1, 330, 300, 512),   # several staged key images, ragged tails
                                        (2, 130, 1, 512), (2, 64, 1, 1024)])
 def test_attention_fwd_bwd(K, B, Nq, Nk, C):
     heads = 8
