@@ -55,6 +55,14 @@ class AttnArgs(C.Structure):
                 ("workspace", c_void_p), ("ws_bytes", c_long)]
 
 
+class Cross1Args(C.Structure):
+    _fields_ = [("v", c_void_p), ("ldv", c_long), ("w_out", c_void_p), ("res", c_void_p), ("ldr", c_long),
+                ("y", c_void_p), ("ldy", c_long), ("dy", c_void_p), ("lddy", c_long), ("u", c_void_p),
+                ("dw_out", c_void_p), ("dv", c_void_p), ("lddv", c_long), ("workspace", c_void_p), ("ws_bytes", c_long),
+                ("B", c_int), ("N", c_int), ("heads", c_int), ("C", c_int),
+                ("drop_p", c_float), ("drop_seed", c_ulonglong)]
+
+
 _SIGS = {
     "dm_abi_version": (c_int, []),
     "dm_target_arch": (C.c_char_p, []),
@@ -81,6 +89,9 @@ _SIGS = {
     "dm_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_attn_bwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "dm_attn_bwd_workspace_bytes": (c_long, [c_int] * 5),
+    "dm_cross1_fwd": (c_int, [C.POINTER(Cross1Args), c_void_p]),
+    "dm_cross1_bwd": (c_int, [C.POINTER(Cross1Args), c_void_p]),
+    "dm_cross1_bwd_workspace_bytes": (c_long, [c_int] * 3),
     "dm_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
     "dm_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dm_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, ConvArgs, GemmArgs, WgradArgs, check
+from ._lib import AttnArgs, ConvArgs, Cross1Args, GemmArgs, WgradArgs, check
 
 BF16 = torch.bfloat16
 
@@ -488,6 +488,51 @@ def attn_onekey_bwd(v, o, d_o, heads, *, drop_p=0.0, drop_seed=0):
     a.scale = 1.0 / ((Cc // heads) ** 0.5)
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
     check(_lib.lib().dm_attn_bwd(C.byref(a), _stream()), "dm_attn_bwd")
+    return dv
+
+
+def cross1_ok(heads: int, Cc: int) -> bool:
+    """Shapes dm_cross1_fwd / dm_cross1_bwd take (include/dm_hip.h)."""
+    return heads == 8 and Cc in (64, 128, 256, 512, 1024)
+
+
+def _cross1_args(v, w_out, N, heads, drop_p, drop_seed):
+    B, Nk, Cc = v.shape
+    assert Nk == 1 and tuple(w_out.shape) == (Cc, Cc)
+    a = Cross1Args()
+    a.v, a.ldv, a.w_out = _p(v), _act(v, "v"), _p(_f32(w_out, "w_out"))
+    a.B, a.N, a.heads, a.C = B, N, heads, Cc
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
+    return a
+
+
+def cross1_fwd(v, w_out, N, heads, *, res=None, out=None, drop_p=0.0, drop_seed=0):
+    """One context token: y[b, n] = res[b, n] + to_out(dropout(v[b]))  in one pass (dm_cross1_fwd, include/dm_hip.h).
+    v: [B,1,C] bf16 (to_v of the token), w_out: the fp32 [C,C] to_out weight, res / out: [B,N,C] bf16."""
+    B, _, Cc = v.shape
+    y = torch.empty((B, N, Cc), dtype=BF16, device=v.device) if out is None else out
+    u = torch.empty((B, heads, Cc), dtype=torch.float32, device=v.device)
+    a = _cross1_args(v, w_out, N, heads, drop_p, drop_seed)
+    if res is not None:
+        a.res, a.ldr = _p(res), _act(res, "res")
+    a.y, a.ldy, a.u = _p(y), _act(y, "y"), _p(u)
+    check(_lib.lib().dm_cross1_fwd(C.byref(a), _stream()), "dm_cross1_fwd")
+    return y
+
+
+def cross1_bwd(dy, v, w_out, heads, *, dw_out=None, drop_p=0.0, drop_seed=0):
+    """Backward of cross1_fwd: returns dv [B,1,C] bf16 and accumulates the to_out weight gradient into ``dw_out``
+    (fp32 [C,C]); the gradient with respect to ``res`` is ``dy`` itself."""
+    B, _, Cc = v.shape
+    N = dy.shape[1]
+    dv = torch.empty((B, 1, Cc), dtype=BF16, device=v.device)
+    u = torch.empty((B, heads, Cc), dtype=torch.float32, device=v.device)
+    ws = workspace(_lib.lib().dm_cross1_bwd_workspace_bytes(B, heads, Cc), v.device)
+    a = _cross1_args(v, w_out, N, heads, drop_p, drop_seed)
+    a.dy, a.lddy, a.u, a.dv, a.lddv = _p(dy), _act(dy, "dy"), _p(u), _p(dv), Cc
+    a.dw_out = _p(_f32(dw_out, "dw_out"))
+    a.workspace, a.ws_bytes = _p(ws), ws.numel()
+    check(_lib.lib().dm_cross1_bwd(C.byref(a), _stream()), "dm_cross1_bwd")
     return dv
 
 

@@ -495,6 +495,18 @@ class CrossAttention(HipModule):
         self.to_v = nn.Linear(context_dim, query_dim, bias=False)
         self.to_out = nn.Linear(query_dim, query_dim, bias=False)
 
+    def _onekey_out(self, vc, B, N, C, res, out, p, seed):
+        """y = res + to_out(dropout(vc)) for a ONE-token context (the attention output does not depend on the
+        queries: softmax over one key).  Fused (dm_cross1_fwd: one pass res -> y, the attention output never reaches
+        memory; returns o = None) or, with FUSE_CROSS1 off / an unsupported width, attn_onekey_fwd + the to_out GEMM."""
+        res = None if res is None else res.view(B, N, C)
+        out = None if out is None else out.view(B, N, C)
+        if FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C):
+            return K.cross1_fwd(vc, self.to_out.weight.detach(), N, self.num_heads, res=res, out=out, drop_p=p,
+                                drop_seed=seed), None
+        o = K.attn_onekey_fwd(vc, N, self.num_heads, drop_p=p, drop_seed=seed)
+        return K.gemm(o, PW.of(self.to_out).fwd, C, res=res, out=out), o
+
     # ctx: bf16 [B, L, Dc]
     def _fwd(self, x, ctx, res=None, out=None, elide=False):
         B, H, W, C = x.shape
@@ -503,9 +515,7 @@ class CrossAttention(HipModule):
             vc = K.gemm(ctx, PW.of(self.to_v).fwd, C)
             p = self.dropout_prob if self.training else 0.0
             seed = next(_SEED) if p > 0 else 0
-            o = K.attn_onekey_fwd(vc, N, self.num_heads, drop_p=p, drop_seed=seed)
-            y = K.gemm(o, PW.of(self.to_out).fwd, C, res=None if res is None else res.view(B, N, C),
-                       out=None if out is None else out.view(B, N, C))
+            y, o = self._onekey_out(vc, B, N, C, res, out, p, seed)
             return y.view(B, H, W, C), (None, ctx, None, None, vc, o, None, p, seed)
         tok = x.view(B, N, C)
         q = K.gemm(tok, PW.of(self.to_q).fwd, C)
@@ -514,24 +524,40 @@ class CrossAttention(HipModule):
         p = self.dropout_prob if self.training else 0.0
         seed = next(_SEED) if p > 0 else 0
         o, lse = K.attn_fwd(q, kc, vc, self.num_heads, drop_p=p, drop_seed=seed)
+        if ctx.shape[1] == 1 and FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C):
+            # one token: same output path as the two-stream schedule (UnetLayer._fwd_attn_overlapped), so the two
+            # schedules stay bit-identical; q / k only feed the log-sum-exp
+            y, o = self._onekey_out(vc, B, N, C, res, out, p, seed)
+            return y.view(B, H, W, C), (tok, ctx, q, kc, vc, o, lse, p, seed)
         y = K.gemm(o, PW.of(self.to_out).fwd, C, res=None if res is None else res.view(B, N, C),
                    out=None if out is None else out.view(B, N, C))
         return y.view(B, H, W, C), (tok, ctx, q, kc, vc, o, lse, p, seed)
 
     def _bwd(self, dy, saved, g: Grads, add=None, need_dctx=False):
         tok, ctx, q, kc, vc, o, lse, p, seed = saved
-        B, N, C = o.shape
+        B, H, W, C = dy.shape
+        N = H * W
         dyt = dy.view(B, N, C)
-        d_o = K.gemm(dyt, PW.of(self.to_out).bwd, C)
-        K.wgrad_side(o, dyt, g.of(self.to_out.weight), None, taps=1)
+        fused = o is None     # _onekey_out took dm_cross1_fwd: one pass over dy gives dv and the to_out weight gradient
+        if fused:
+            dv = K.cross1_bwd(dyt, vc, self.to_out.weight.detach(), self.num_heads, dw_out=g.of(self.to_out.weight),
+                              drop_p=p, drop_seed=seed)
+        else:
+            d_o = K.gemm(dyt, PW.of(self.to_out).bwd, C)
+            K.wgrad_side(o, dyt, g.of(self.to_out.weight), None, taps=1)
         if tok is None:  # elided form: dq = dk = 0 exactly, so to_q / to_k get no gradient and dx is just `add`
-            dv = K.attn_onekey_bwd(vc, o, d_o, self.num_heads, drop_p=p, drop_seed=seed)
+            if not fused:
+                dv = K.attn_onekey_bwd(vc, o, d_o, self.num_heads, drop_p=p, drop_seed=seed)
             K.wgrad_side(ctx, dv, g.of(self.to_v.weight), None, taps=1)
             g.of(self.to_q.weight), g.of(self.to_k.weight)  # (allocate the zero gradients for autograd callers)
             if g.dctx is not None:   # dk = 0: the context gradient comes through to_v alone
                 self._add_dctx(g, None, dv)
             return add, None
-        dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
+        if fused:   # one key: dq and dk are exact zeros (dm_attn_bwd writes the same zeros); the rest runs as always
+            dq = torch.zeros((B, N, C), dtype=torch.bfloat16, device=dy.device)
+            dk = torch.zeros_like(dv)
+        else:
+            dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
         K.wgrad_side(tok, dq, g.of(self.to_q.weight), None, taps=1)
         K.wgrad_side(ctx, dk, g.of(self.to_k.weight), None, taps=1)
         K.wgrad_side(ctx, dv, g.of(self.to_v.weight), None, taps=1)
@@ -645,6 +671,11 @@ OVERLAP_DEAD_ATTENTION = [os.environ.get("DM_OVERLAP_DEAD_ATTENTION", "1") != "0
 # there the auxiliary stream takes to_q, to_k, the log-sum-exp and, in the backward, the whole cross-attention backward
 # (DM_OVERLAP_CROSS_ONLY=0: only layers with a self-attention block are scheduled this way).
 OVERLAP_CROSS_ONLY = [os.environ.get("DM_OVERLAP_CROSS_ONLY", "1") != "0"]
+# One-token context: attention output + to_out + residual as ONE streaming pass (dm_cross1_fwd / dm_cross1_bwd,
+# include/dm_hip.h) instead of attn_onekey_fwd -> GEMM and, backward, GEMM -> weight gradient -> attn_onekey_bwd.
+# Same dropout words, same results up to bf16 rounding of the (no longer materialised) attention output.
+# DM_FUSE_CROSS1=0 restores the three-kernel form.
+FUSE_CROSS1 = [os.environ.get("DM_FUSE_CROSS1", "1") != "0"]
 KEEP_DEAD_DX = [False]   # tests: keep the (zero) input gradient of the overlapped backward branch in UnetLayer._dead_dx
 
 
@@ -728,8 +759,7 @@ class UnetLayer(HipModule):
             q = K.gemm(tok, PW.of(ca.to_q).fwd, C)
             kc = K.gemm(ctx, PW.of(ca.to_k).fwd, C)
             _, lse = K.attn_fwd(q, kc, vc, ca.num_heads, drop_p=p_c, drop_seed=seed_c)
-        o = K.attn_onekey_fwd(vc, N, ca.num_heads, drop_p=p_c, drop_seed=seed_c)
-        y = K.gemm(o, PW.of(ca.to_out).fwd, C, res=r.view(B, N, C), out=None if dst is None else dst.view(B, N, C))
+        y, o = ca._onekey_out(vc, B, N, C, r, dst, p_c, seed_c)
         return y.view(B, H, W, C), s_a, (tok, ctx, q, kc, vc, o, lse, p_c, seed_c)
 
     def _bwd(self, dy, d_skip, saved, g: Grads, dts=None, need_dx=True):

@@ -196,6 +196,34 @@ int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
 /* Scratch the single-pass backward wants for this shape (two fp32 partial copies of dq), or 0 when the shape has none. */
 long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd);
 
+/* One-token cross-attention, output side, as one streaming pass.  Replaces, for a single context token (the CLIP-table
+ * configuration: context [B, 512] -> one key, unet.py:197-198), F.scaled_dot_product_attention + to_out + the residual
+ * add of CrossAttention.forward / UnetLayer.forward (unet.py:205-220, 274) and their autograd backward.
+ * With one key the softmax is exactly 1, so  y[b, n, :] = res[b, n, :] + sum_h Z[b, n, h] * U[b, h, :]  with
+ * U[b, h, :] = w_out[:, head h] . v[b, head h] / keep  and Z the dropout mask of the one probability per (pixel, head)
+ * -- the same words dm_attn_fwd draws with Nk == 1, so the two formulations are interchangeable under one seed.
+ * dm_cross1_fwd: writes U into `u` (fp32 [B, heads, C]) and streams res -> y (res NULL: no residual).
+ * dm_cross1_bwd: streams dy once into dU (written to `u`), then dw_out += sum_b dU (x) v (dw_out NULL: skipped) and
+ *   dv[b, ci] = sum_co dU[b, h(ci), co] * w_out[co, ci].  Fixed summation order (bit-reproducible).  The gradient with
+ *   respect to res is dy itself; the query / key inputs of the attention get exactly zero (dm_attn_bwd, Nk == 1).
+ * heads must be 8 and C one of 64, 128, 256, 512, 1024 (DM_ERR_ARG otherwise: use dm_attn_* + dm_gemm). */
+typedef struct dm_cross1_args {
+  const void* v; long ldv;          /* bf16 [B, C]: to_v(context) of the one token */
+  const float* w_out;               /* fp32 [C, C] (out, in): the to_out weight (master copy) */
+  const void* res; long ldr;        /* bf16 [B*N, C], row stride ldr (forward; NULL = none) */
+  void* y; long ldy;                /* bf16 [B*N, C] (forward) */
+  const void* dy; long lddy;        /* bf16 [B*N, C] (backward) */
+  float* u;                         /* fp32 [B, heads, C]: U (forward) / dU (backward), caller's buffer */
+  float* dw_out;                    /* fp32 [C, C], accumulated += (backward; NULL = skip) */
+  void* dv; long lddv;              /* bf16 [B, C] (backward) */
+  void* workspace; long ws_bytes;   /* backward: dm_cross1_bwd_workspace_bytes() bytes */
+  int B, N, heads, C;
+  float drop_p; unsigned long long drop_seed;
+} dm_cross1_args;
+int dm_cross1_fwd(const dm_cross1_args* args, dm_stream_t stream);
+int dm_cross1_bwd(const dm_cross1_args* args, dm_stream_t stream);
+long dm_cross1_bwd_workspace_bytes(int B, int heads, int C);
+
 /* ------------------------------------------------------------------ layout / elementwise */
 /* NCHW fp32 -> NHWC bf16, channels zero-padded to Cpad (UNET.forward entry, unet.py:344). */
 int dm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, long ldy, int Cpad,

@@ -333,6 +333,53 @@ def test_attention_single_pass_backward_matches_two_kernel_backward(K, B, p):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("B,N,C,p", [(2, 2304, 128, 0.0), (2, 2304, 128, 0.1), (3, 1000, 64, 0.25), (2, 576, 256, 0.1),
+                                     (2, 70, 512, 0.1), (2, 33, 1024, 0.1)])
+def test_cross1_matches_onekey_attention_plus_to_out(K, B, N, C, p):
+    """dm_cross1_fwd / dm_cross1_bwd (one context token: dropout(v) through to_out in one streaming pass) against the
+    formulation they replace, run with the SAME seed (the dropout words are shared): attn_onekey_fwd -> gemm(+res) in the
+    forward; to_out data gradient -> attn_onekey_bwd, and the to_out weight gradient, in the backward.  Also against plain
+    fp32 torch through the extracted mask."""
+    heads, seed = 8, 4242
+    v = q16(rnd(B, 1, C, seed=1)).to(torch.bfloat16)
+    w = rnd(C, C, seed=2, scale=C ** -0.5).contiguous()
+    res = q16(rnd(B, N, C, seed=3)).to(torch.bfloat16)
+    dy = q16(rnd(B, N, C, seed=4)).to(torch.bfloat16)
+    # the replaced path
+    o = K.attn_onekey_fwd(v, N, heads, drop_p=p, drop_seed=seed)
+    y_ref = K.gemm(o, K.pack_weight(w), C, res=res)
+    d_o = K.gemm(dy, K.pack_weight(w, transpose=True), C)
+    dv_ref = K.attn_onekey_bwd(v, o, d_o, heads, drop_p=p, drop_seed=seed)
+    dw_ref = torch.zeros(C, C, device=dev())
+    K.wgrad(o, dy, dw_ref, None, taps=1)
+    # the fused path
+    y = K.cross1_fwd(v, w, N, heads, res=res, drop_p=p, drop_seed=seed)
+    assert K.last_variant().startswith("cross1_fwd")
+    dw = torch.zeros(C, C, device=dev())
+    dv = K.cross1_bwd(dy, v, w, heads, dw_out=dw, drop_p=p, drop_seed=seed)
+    assert_close(y.float(), y_ref.float(), 1.5e-2, "y vs onekey + to_out")
+    assert_close(dv.float(), dv_ref.float(), 1.5e-2, "dv vs onekey bwd")
+    assert_close(dw, dw_ref, 1.5e-2, "dWout vs wgrad")
+    # fp32 torch with the mask the kernels drew (o is mask * v / keep, exactly representable pattern: o != 0 <=> kept)
+    hd = C // heads
+    z = (o.float().view(B, N, heads, hd).abs().sum(-1) > 0).float() if p > 0 else torch.ones(B, N, heads, device=dev())
+    keep = 1.0 - round(p * 32768) / 32768.0
+    of = (z / keep).unsqueeze(-1) * v.float().view(B, 1, heads, hd)
+    y32 = res.float() + of.reshape(B, N, C) @ w.t()
+    assert_close(y.float(), y32, BF, "y vs fp32")
+    do32 = dy.float() @ w
+    dv32 = ((z / keep).unsqueeze(-1) * do32.view(B, N, heads, hd)).sum(1).reshape(B, 1, C)
+    dw32 = torch.einsum("bno,bni->oi", dy.float(), of.reshape(B, N, C))
+    assert_close(dv.float(), dv32, BF, "dv vs fp32")
+    assert_close(dw, dw32, 2e-3, "dWout vs fp32")
+    # accumulation (+=), bit-reproducibility, and the no-residual form
+    dw2 = dw.clone()
+    dvb = K.cross1_bwd(dy, v, w, heads, dw_out=dw2, drop_p=p, drop_seed=seed)
+    assert torch.equal(dvb, dv) and torch.equal(dw2, 2 * dw)
+    y0 = K.cross1_fwd(v, w, N, heads, drop_p=p, drop_seed=seed)
+    assert_close(y0.float(), (y32 - res.float()), BF, "y without residual")
+
+
 # ------------------------------------------------------------------ layout / elementwise
 def test_layout_and_elementwise(K):
     x = rnd(2, 3, 16, 16, seed=1)
