@@ -43,7 +43,12 @@ __global__ __launch_bounds__(256) void cross1_u_kernel(const Cross1Params p) {
     const float* wr = p.w + (long)co * p.C + h * p.hd;
     const bf16* vr = p.v + b * p.ldv + h * p.hd;
     float s = 0.f;
-    for (int j = 0; j < p.hd; ++j) s += wr[j] * (float)vr[j];
+    for (int j = 0; j < p.hd; j += 8) {   // hd is a multiple of 8 (C % 64 == 0, eight heads)
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + j), w1 = *reinterpret_cast<const f32x4*>(wr + j + 4);
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vr + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += w0[e] * (float)vv[e] + w1[e] * (float)vv[4 + e];
+    }
     p.u[i] = s * p.inv_keep;
   }
 }
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(256) void cross1_bwd_kernel(const Cross1Params p) {
       for (int j = 0; j < 8; ++j) acc[h][j] += zf * (float)d[j];
     }
   }
-  for (int h = 0; h < NH; ++h) {
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {   // (unrolled: acc[h] must stay a register index)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) sAcc[qs * p.C + c8 + j] = acc[h][j];
@@ -170,29 +176,43 @@ __global__ __launch_bounds__(256) void cross1_du_kernel(const Cross1Params p, in
   const long n = (long)p.B * H8 * p.C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += p.ws[k * n + i];
+#pragma unroll 8
+    for (int k = 0; k < nblk; ++k) s += p.ws[k * n + i];   // independent loads, one fixed order of additions
     p.u[i] = s;
   }
 }
 
-// threads [0, C*C): dw[co][ci] += sum_b dU[b][h(ci)][co] * v[b][ci];  threads [C*C, C*C + B*C): dv[b][ci]
+// outputs [0, C*C): dw[co][ci] += sum_b dU[b][h(ci)][co] * v[b][ci];  outputs [C*C, C*C + B*C): dv[b][ci] =
+// sum_co dU[b][h(ci)][co] * w[co][ci].  Four lanes per output (adjacent outputs = adjacent ci: the v / w reads stay
+// coalesced, the dU reads are near-broadcasts), each lane an unrolled strided share of the reduction so that eight
+// independent loads are in flight, combined by a fixed xor butterfly.  (One thread per output with a plain loop was a
+// serial chain of dependent L2 loads: 64 us per call.)
 __global__ __launch_bounds__(256) void cross1_grads_kernel(const Cross1Params p) {
   const long nw = (long)p.C * p.C, n = nw + (long)p.B * p.C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+  const int sub = threadIdx.x & 3;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 2; i < n; i += ((long)gridDim.x * 256) >> 2) {
+    float s = 0.f;
     if (i < nw) {
-      if (!p.dw) continue;
       const int ci = (int)(i % p.C), co = (int)(i / p.C), h = ci / p.hd;
-      float s = 0.f;
-      for (int b = 0; b < p.B; ++b) s += p.u[((long)b * H8 + h) * p.C + co] * (float)p.v[(long)b * p.ldv + ci];
-      p.dw[i] += s;
+      if (p.dw) {
+        const float* du = p.u + (long)h * p.C + co;
+        const bf16* vv = p.v + ci;
+#pragma unroll 8
+        for (int b = sub; b < p.B; b += 4) s += du[(long)b * H8 * p.C] * (float)vv[(long)b * p.ldv];
+      }
     } else {
       const long k = i - nw;
       const int ci = (int)(k % p.C), h = ci / p.hd;
-      const long b = k / p.C;
-      const float* du = p.u + (b * H8 + h) * p.C;
-      float s = 0.f;
-      for (int co = 0; co < p.C; ++co) s += du[co] * p.w[(long)co * p.C + ci];
-      p.dv[b * p.lddv + ci] = (bf16)s;
+      const float* du = p.u + ((k / p.C) * H8 + h) * p.C;
+      const float* wc = p.w + ci;
+#pragma unroll 8
+      for (int co = sub; co < p.C; co += 4) s += du[co] * wc[(long)co * p.C];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (sub == 0) {
+      if (i < nw) { if (p.dw) p.dw[i] += s; }
+      else { const long k = i - nw; p.dv[(k / p.C) * p.lddv + (k % p.C)] = (bf16)s; }
     }
   }
 }
@@ -262,7 +282,7 @@ extern "C" int dm_cross1_bwd(const dm_cross1_args* a, dm_stream_t stream) {
   DM_LAUNCH_CHECK();
   hipLaunchKernelGGL(cross1_du_kernel, dim3(blocks_for((long)p.B * H8 * p.C)), dim3(256), 0, st, p, gx);
   DM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cross1_grads_kernel, dim3(blocks_for((long)p.C * p.C + (long)p.B * p.C)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(cross1_grads_kernel, dim3(blocks_for(4 * ((long)p.C * p.C + (long)p.B * p.C))), dim3(256), 0, st, p);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }
