@@ -315,13 +315,19 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if (world > 1 or a.rehearse_dp) and os.environ.get("DM_RESERVE_STREAMS", "1") != "0":
+        from diffusion_model_amd import kernels as K0
+        K0.reserve_streams(dev)   # the step's own streams take their hardware queues before RCCL creates its streams
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
-    elif a.rehearse_dp:
+    elif a.rehearse_dp and os.environ.get("DM_REHEARSE_MODE", "") != "hooksonly":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if os.environ.get("DM_PG_LAZY", "") == "1":
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from diffusion_model_amd.ema import ModelEmaV2
     from diffusion_model_amd.sampler import CFGSampler
@@ -334,9 +340,9 @@ def main():
     ema = ModelEmaV2(model, decay=0.995)
     tr = Trainer(model, sched, lr=5e-5, weight_decay=1e-4, betas=(0.9, 0.99), clip=1.0, ema_decay=0.995,
                  accum=2, total_steps=100 * 79, start_step=20 * 40, low_t_weight=0.01, ema=ema,
-                 distributed=world > 1 or a.rehearse_dp)
+                 distributed=world > 1 or (a.rehearse_dp and os.environ.get("DM_REHEARSE_MODE", "") != "pgonly"))
     if a.rehearse_dp and tr.buckets is not None:
-        tr.buckets.force = True
+        tr.buckets.force = os.environ.get("DM_REHEARSE_NOFORCE", "") != "1"   # (=1: process group and hooks, no collective)
     batches = [synth_batch(a.batch, rank * 2 + i, dev, table, sched) for i in range(2)]
 
     def opt_step():
