@@ -168,7 +168,20 @@ def _dp_worker(rank, world, port, q):
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         want = sum(gathered)
-        q.put((rank, bool(torch.allclose(fp.grad, want, atol=1e-5)), float((fp.grad - want).abs().max())))
+        ok = bool(torch.allclose(fp.grad, want, atol=1e-5))
+        err = float((fp.grad - want).abs().max())
+        # the one-collective form (DM_DP_BUCKETS=1): nothing until the last stage, then the whole buffer
+        os.environ["DM_DP_BUCKETS"] = "1"
+        bk1 = GradBuckets(fp, unet_stage_names(m))
+        fp.grad.copy_(local)
+        names = [st for st, _ in unet_stage_names(m)]
+        for st in names[:-1]:
+            bk1.launch(st)
+        ok = ok and not bk1.pending
+        bk1.launch(names[-1])
+        bk1.wait()
+        ok = ok and bool(torch.allclose(fp.grad, want, atol=1e-5))
+        q.put((rank, ok, max(err, float((fp.grad - want).abs().max()))))
     finally:
         dist.destroy_process_group()
 
