@@ -353,6 +353,9 @@ def reserve_streams(device) -> None:
     ONE hardware queue and the step lost its stream overlap: +0.9 ms (6 %) per optimizer step for an IDLE communicator
     (tools/dp_ab.sh).  Call before torch.distributed.init_process_group(..., device_id=...) / the first collective."""
     dev = torch.device(device)
+    if os.environ.get("DM_RESERVE_MODE", "") != "nomain":   # (measurement switch, tools/hwq_ab2.sh)
+        torch.zeros(1, device=dev)          # the main (current) stream first: streams get their queue at first USE
+        torch.cuda.current_stream(dev).synchronize()
     for st, _ in (_side_stream(dev), aux_stream(dev)):
         with torch.cuda.stream(st):
             torch.zeros(1, device=dev)
