@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256) void attn_onekey_fwd_kernel(const AttnParams p
       if ((tid % sub) == 0) p.lse[(long)bh * p.Nq + q] = s;
     }
     const bool keep = !drop || onekey_keep(p, seed_eff, bh, q);
-    *reinterpret_cast<bf16x8*>(p.o + row * p.ldo + c8) = keep ? (drop ? vs : vr) : vz;
+    if (p.o) *reinterpret_cast<bf16x8*>(p.o + row * p.ldo + c8) = keep ? (drop ? vs : vr) : vz;
   }
 }
 // ws: [gridDim.x][B][C] fp32 per-block partial sums of dV (plain stores: no memset before, no atomics, a fixed
@@ -1499,7 +1499,7 @@ __global__ void attn_onekey_finish_kernel(const AttnParams p, const float* __res
 }
 bool onekey_ok(const AttnParams& p) {
   const int C = p.H * p.hd;
-  return p.Nk == 1 && C <= 2048 && 256 % (C >> 3) == 0 && (p.ldo & 7) == 0 && (!p.dq || ((p.lddq & 7) == 0 && (p.lddo & 7) == 0));
+  return p.Nk == 1 && C <= 2048 && 256 % (C >> 3) == 0 && (!p.o || (p.ldo & 7) == 0) && (!p.dq || ((p.lddq & 7) == 0 && (p.lddo & 7) == 0));
 }
 
 bool small_ok(const AttnParams& p) {
@@ -1508,7 +1508,9 @@ bool small_ok(const AttnParams& p) {
 }
 
 int fill(AttnParams& p, const dm_attn_args* a, bool bwd) {
-  DM_REQUIRE(a && a->v && a->o);
+  // With ONE key and the log-sum-exp wanted, the forward's output may be declined (o = NULL): a caller that forms the
+  // attention output elsewhere (dm_cross1_fwd) then pays for the q.k pass alone.
+  DM_REQUIRE(a && a->v && (a->o || (!bwd && a->Nk == 1 && a->lse && a->q && a->k)));
   DM_REQUIRE(a->hd == 8 || a->hd == 16 || a->hd == 32 || a->hd == 64 || a->hd == 128);
   DM_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
   // With ONE key the output does not depend on q or k (softmax over one element), so a caller that has no use for
@@ -1569,7 +1571,7 @@ extern "C" int dm_attn_fwd(const dm_attn_args* a, dm_stream_t stream) {
   AttnParams p{};
   const int rc = fill(p, a, false);
   if (rc != DM_OK) return rc;
-  if (!p.q && !onekey_ok(p)) return DM_ERR_ARG;  // the q-less form exists only on the one-token path
+  if ((!p.q || !p.o) && !onekey_ok(p)) return DM_ERR_ARG;  // the q-less and o-less forms exist only on the one-token path
   if (onekey_ok(p)) {
     const int QPB = 256 / ((p.H * p.hd) >> 3);
     int gx = (p.Nq + QPB - 1) / QPB;

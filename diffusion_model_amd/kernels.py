@@ -439,17 +439,18 @@ def _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed):
     hd = Cc // heads
     a = AttnArgs()
     a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = _p(q), _act(q, "q"), _p(k), _act(k, "k"), _p(v), _act(v, "v")
-    a.o, a.ldo, a.lse = _p(o), _act(o, "o"), _p(_f32(lse, "lse"))
+    a.o, a.ldo, a.lse = _p(o), (_act(o, "o") if o is not None else 0), _p(_f32(lse, "lse"))
     a.B, a.heads, a.Nq, a.Nk, a.hd = B, heads, Nq, Nk, hd
     a.scale = 1.0 / (hd ** 0.5)
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed)
     return a
 
 
-def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0):
-    """q: [B,Nq,C], k/v: [B,Nk,C] (views into a fused qkv buffer are fine) -> (o [B,Nq,C], lse [B,heads,Nq])."""
+def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0, want_o=True):
+    """q: [B,Nq,C], k/v: [B,Nk,C] (views into a fused qkv buffer are fine) -> (o [B,Nq,C], lse [B,heads,Nq]).
+    ``want_o=False`` (one key only): just the log-sum-exp, o is returned as None (dm_hip.h)."""
     B, Nq, Cc = q.shape
-    o = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device)
+    o = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if want_o else None
     lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
     check(_lib.lib().dm_attn_fwd(C.byref(a), _stream()), "dm_attn_fwd")

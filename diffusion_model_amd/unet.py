@@ -523,8 +523,9 @@ class CrossAttention(HipModule):
         vc = K.gemm(ctx, PW.of(self.to_v).fwd, C)
         p = self.dropout_prob if self.training else 0.0
         seed = next(_SEED) if p > 0 else 0
-        o, lse = K.attn_fwd(q, kc, vc, self.num_heads, drop_p=p, drop_seed=seed)
-        if ctx.shape[1] == 1 and FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C):
+        one = ctx.shape[1] == 1 and FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C)
+        o, lse = K.attn_fwd(q, kc, vc, self.num_heads, drop_p=p, drop_seed=seed, want_o=not one)
+        if one:
             # one token: same output path as the two-stream schedule (UnetLayer._fwd_attn_overlapped), so the two
             # schedules stay bit-identical; q / k only feed the log-sum-exp
             y, o = self._onekey_out(vc, B, N, C, res, out, p, seed)
@@ -758,7 +759,8 @@ class UnetLayer(HipModule):
             tok = xa.view(B, N, C)
             q = K.gemm(tok, PW.of(ca.to_q).fwd, C)
             kc = K.gemm(ctx, PW.of(ca.to_k).fwd, C)
-            _, lse = K.attn_fwd(q, kc, vc, ca.num_heads, drop_p=p_c, drop_seed=seed_c)
+            # (only the log-sum-exp: the attention output itself is formed on the main stream, _onekey_out)
+            _, lse = K.attn_fwd(q, kc, vc, ca.num_heads, drop_p=p_c, drop_seed=seed_c, want_o=False)
         y, o = ca._onekey_out(vc, B, N, C, r, dst, p_c, seed_c)
         return y.view(B, H, W, C), s_a, (tok, ctx, q, kc, vc, o, lse, p_c, seed_c)
 

@@ -190,7 +190,8 @@ typedef struct dm_attn_args {
  * (unet.py:119-126,136,165-172,214).
  * One key (Nk == 1, the CLIP context of unet.py:205-214): the softmax is identically 1, so o = dropout(v), dq = dk = 0 and
  * lse = scale * q.k exactly; a caller with no use for lse may pass q = k = lse = NULL (forward) and additionally
- * dq = dk = NULL (backward: only dv is produced).  Any other NULL is DM_ERR_ARG. */
+ * dq = dk = NULL (backward: only dv is produced); a caller that wants ONLY lse (the output formed elsewhere:
+ * dm_cross1_fwd) may pass o = NULL (forward).  Any other NULL is DM_ERR_ARG. */
 int dm_attn_fwd(const dm_attn_args* args, dm_stream_t stream);
 int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
 /* Scratch the single-pass backward wants for this shape (two fp32 partial copies of dq), or 0 when the shape has none. */

@@ -378,6 +378,12 @@ def test_cross1_matches_onekey_attention_plus_to_out(K, B, N, C, p):
     assert torch.equal(dvb, dv) and torch.equal(dw2, 2 * dw)
     y0 = K.cross1_fwd(v, w, N, heads, drop_p=p, drop_seed=seed)
     assert_close(y0.float(), (y32 - res.float()), BF, "y without residual")
+    # the log-sum-exp-only form of the one-key forward (o declined) returns the same lse as the full call
+    qq = q16(rnd(B, N, C, seed=5)).to(torch.bfloat16)
+    kk = q16(rnd(B, 1, C, seed=6)).to(torch.bfloat16)
+    o_full, lse_full = K.attn_fwd(qq, kk, v, heads, drop_p=p, drop_seed=seed)
+    o_none, lse_only = K.attn_fwd(qq, kk, v, heads, drop_p=p, drop_seed=seed, want_o=False)
+    assert o_none is None and torch.equal(lse_only, lse_full) and torch.equal(o_full, o)
 
 
 # ------------------------------------------------------------------ layout / elementwise
