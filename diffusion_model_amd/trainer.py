@@ -102,14 +102,20 @@ class GradBuckets:
     def launch(self, stage: str) -> None:
         if self.world == 1 and not self.force:   # (force: rehearse the collective path on one rank, bench --rehearse-dp)
             return
+        # DM_DP_SYNC=1 (measurement switch): blocking-style collectives.  They are issued with the weight-gradient
+        # stream current (unet hook -> kernels.call_on_side), so "blocking" orders that stream behind them, not the host
+        # and not the main stream.
+        sync = os.environ.get("DM_DP_SYNC", "") == "1"
         if self.single:
             if stage == self.last_stage:
-                self.pending.append(self.dist.all_reduce(self.fp.grad, op=self.dist.ReduceOp.SUM, group=self.pg,
-                                                         async_op=True))
+                w = self.dist.all_reduce(self.fp.grad, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=not sync)
+                if not sync:
+                    self.pending.append(w)
             return
         for a, b in self.stage_ranges[stage]:
-            self.pending.append(self.dist.all_reduce(self.fp.grad[a:b], op=self.dist.ReduceOp.SUM,
-                                                     group=self.pg, async_op=True))
+            w = self.dist.all_reduce(self.fp.grad[a:b], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=not sync)
+            if not sync:
+                self.pending.append(w)
 
     def wait(self) -> None:
         for w in self.pending:
