@@ -14,6 +14,12 @@ namespace {
 constexpr int PART_LDS = 512;  // (split, group) partials staged in LDS by the apply kernels
 constexpr int MAX_C = 1024;    // widest GroupNorm (latent-model widths, utils.py:145-156); 256 threads x 8 channels x rows
 struct Wf { float n, mean, m2; };
+__device__ __forceinline__ bf16x8 zero8_norm() {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)0.f;
+  return r;
+}
 __device__ __forceinline__ Wf wf_merge(Wf a, Wf b) {
   const float n = a.n + b.n;
   if (n == 0.f) return a;
@@ -149,6 +155,104 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     for (int u = 0; u < 4; ++u) one(v[u], pix + u * ppi);
   }
   for (; pix < p_end; pix += ppi) one(*reinterpret_cast<const bf16x8*>(xb + (long)pix * ldx), pix);
+}
+
+// ---------------------------------------------------------------- one pass: the (sample, group) slab lives in registers
+// GroupNorm(8, C) on the UNet's tensors: one (sample, group) slab is at most 8..32 channels x 9216 pixels x 2 B = 144 KiB,
+// which a 1024-thread workgroup holds in registers (9 sixteen-byte pieces per thread).  One workgroup per (sample, group)
+// reads its slab ONCE, reduces the statistics through LDS, and writes silu(affine(x)) from the registers: 4 B/elem of
+// HBM traffic instead of the 6 B/elem of gn_stats_kernel + gn_apply_kernel.  A slab is a 16..64-byte piece of every
+// pixel row (NHWC), i.e. a strided stream that uses only part of each 128-byte line; the other groups of the same sample
+// use the rest, so the eight workgroups of a sample are given consecutive slots on ONE XCD (workgroup id -> XCD is
+// id mod 8) and meet in that XCD's L2.
+constexpr int OP_THREADS = 1024, OP_MAXP = 9;
+__global__ __launch_bounds__(OP_THREADS) void gn_onepass_fwd_kernel(const bf16* __restrict__ x, long ldx,
+                                                                     const float* __restrict__ chan_add,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta,
+                                                                     float* __restrict__ stats, bf16* __restrict__ y, long ldy,
+                                                                     int B, int HW, int C, float eps, int act) {
+  __shared__ Wf red[OP_THREADS / 64];
+  __shared__ float s_ms[2];
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3, g = jj & 7, b = (jj >> 3) * 8 + xcd;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cpg = C >> 3, ppp = cpg >> 3;          // channels per group; 16-byte pieces per pixel of this group
+  const int sub = tid % ppp, c0 = g * cpg + sub * 8;
+  const int npieces = HW * ppp;
+  float add[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) add[j] = chan_add ? chan_add[(long)b * C + c0 + j] : 0.f;
+  const bf16* xb = x + (long)b * HW * ldx + c0;
+  bf16x8 v[OP_MAXP];
+#pragma unroll
+  for (int k = 0; k < OP_MAXP; ++k) {
+    const int i = tid + k * OP_THREADS;
+    v[k] = zero8_norm();
+    if (i < npieces) v[k] = *reinterpret_cast<const bf16x8*>(xb + (long)(i / ppp) * ldx);
+  }
+  float s = 0.f, ss = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < OP_MAXP; ++k) {
+    if (tid + k * OP_THREADS < npieces) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[k][j] + add[j];
+        s += f; ss += f * f;
+      }
+      cnt += 8.f;
+    }
+  }
+  Wf w;
+  w.n = cnt;
+  w.mean = cnt > 0.f ? s / cnt : 0.f;
+  w.m2 = cnt > 0.f ? fmaxf(ss - s * w.mean, 0.f) : 0.f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Wf t;
+    t.n = __shfl_xor(w.n, o, 64); t.mean = __shfl_xor(w.mean, o, 64); t.m2 = __shfl_xor(w.m2, o, 64);
+    w = wf_merge(w, t);
+  }
+  if (lane == 0) red[wave] = w;
+  __syncthreads();
+  if (tid == 0) {
+    Wf acc = red[0];
+    for (int i = 1; i < OP_THREADS / 64; ++i) acc = wf_merge(acc, red[i]);
+    const float rstd = rsqrtf(acc.m2 / acc.n + eps);
+    s_ms[0] = acc.mean; s_ms[1] = rstd;
+    if (stats) { stats[((long)b * 8 + g) * 2] = acc.mean; stats[((long)b * 8 + g) * 2 + 1] = rstd; }
+  }
+  __syncthreads();
+  const float mean = s_ms[0], rstd = s_ms[1];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = gamma[c0 + j] * rstd;
+    sh[j] = beta[c0 + j] + (add[j] - mean) * sc[j];
+  }
+  bf16* yb = y + (long)b * HW * ldy + c0;
+#pragma unroll
+  for (int k = 0; k < OP_MAXP; ++k) {
+    const int i = tid + k * OP_THREADS;
+    if (i < npieces) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = (float)v[k][j] * sc[j] + sh[j];
+        o[j] = (bf16)(act ? dm_silu(z) : z);
+      }
+      *reinterpret_cast<bf16x8*>(yb + (long)(i / ppp) * ldy) = o;
+    }
+  }
+}
+bool gn_onepass_ok(int HW, int C, int G) {
+  const char* e = getenv("DM_GN_ONEPASS");   // "0": the two-pass kernels (read per call: tests switch it at run time)
+  const bool on = !(e && e[0] == '0');
+  const int cpg = G > 0 ? C / G : 0;
+  // 16-channel groups and wider (32-byte pieces and up).  With 8-channel groups (64 channels) a slab is a 16-byte piece
+  // of every 128-byte pixel row and the strided stream loses: 64ch@96x96, B=64: 55.7 us against 44.9 us in two passes;
+  // 128ch@48x48 30.4 -> 24.0 us, 256ch@24x24 19.5 -> 14.2, 256ch@48x48 44.7 -> 34.9 (tools/hbmbench.py).
+  return on && G == 8 && cpg >= 16 && cpg % 8 == 0 && OP_THREADS % (cpg / 8) == 0 && (long)HW * (cpg / 8) <= (long)OP_THREADS * OP_MAXP;
 }
 
 // grid (B): merge the sample's (split, group) partials -> stats[b][g] = {mean, rstd}; scale[b][c] = gamma*rstd,
@@ -428,6 +532,14 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
   DM_REQUIRE(ws_bytes >= dm_gn_workspace_bytes(B, HW, C, G));
   const int ns = pick_split(B, HW, false);
   hipStream_t st = (hipStream_t)stream;
+  if (gn_onepass_ok(HW, C, G)) {
+    dm_set_variant("gn_onepass_fwd");
+    hipLaunchKernelGGL(gn_onepass_fwd_kernel, dim3(((B + 7) / 8) * 64), dim3(OP_THREADS), 0, st, (const bf16*)x, ldx,
+                       chan_add, gamma, beta, stats, (bf16*)y, ldy, B, HW, C, eps, act_silu);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  dm_set_variant("gn_stats+gn_apply");
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (float*)workspace, HW, C, G, ns);
   DM_LAUNCH_CHECK();

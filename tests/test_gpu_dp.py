@@ -43,11 +43,13 @@ def _worker(rank, world, port, q):
 
 def _worker_body(rank, world, port, q):
     import datetime
+    import faulthandler
     import torch.distributed as dist
+    faulthandler.dump_traceback_later(200, exit=False)   # a rank that hangs says where (stderr) before the parent gives up
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     try:
         from diffusion_model_amd import kernels as K
         from diffusion_model_amd.trainer import Trainer
@@ -87,11 +89,11 @@ def test_data_parallel_two_ranks_match_gradient_accumulation():
     for p in procs:
         p.start()
     try:
-        res = [q.get(timeout=100) for _ in procs]
+        res = [q.get(timeout=240) for _ in procs]   # (a cold box pages the libraries in again for every child)
     except Exception:
         for p in procs:
             p.kill()
-        raise AssertionError("a data-parallel rank did not report within 100 s (exit codes %s)" % [p.exitcode for p in procs])
+        raise AssertionError("a data-parallel rank did not report within 240 s (exit codes %s)" % [p.exitcode for p in procs])
     for r in res:
         assert "error" not in r, r["error"]
     res = sorted(res, key=lambda r: r["rank"])

@@ -479,6 +479,28 @@ def test_adamw_clip_ema_matches_torch(K):
     assert_close(po, pr2.detach(), 1e-6, "oracle adamw", atol_frac=1e-7)
 
 
+def test_gn_onepass_forward_full_size_and_dispatch(K):
+    """GroupNorm forward in ONE pass (gn_onepass_fwd_kernel: a (sample, group) slab in the registers of one workgroup)
+    at a slab of the maximum size (256 channels @ 48x48: nine pieces per thread), with more than eight samples (two
+    rounds of the sample -> XCD placement), a channel-add and an output that is a slice of a wider buffer; 64-channel
+    tensors (8-channel groups) must keep the two-pass kernels.  Both against fp32 torch, and against each other."""
+    import os
+    B, H, C = 9, 48, 256
+    x = q16(rnd(B, C, H, H, seed=1) * 1.3 - 0.2)
+    gamma, beta, ca = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, seed=4)
+    ref = F.silu(F.group_norm(x + ca[:, :, None, None], 8, gamma, beta, 1e-5))
+    buf = torch.full((B, H, H, 2 * C), 3.0, dtype=torch.bfloat16, device=dev())
+    y, stats = K.gn_silu_fwd(nhwc(x), gamma, beta, 8, chan_add=ca, out=buf[..., C:])
+    assert K.last_variant() == "gn_onepass_fwd"
+    assert_close(nchw(buf[..., C:].contiguous()), ref, BF, "one-pass gn fwd")
+    assert float((buf[..., :C].float() - 3.0).abs().max()) == 0.0
+    xg = (x + ca[:, :, None, None]).view(B, 8, -1)
+    assert_close(stats[..., 0], xg.mean(-1), 1e-4, "mean", atol_frac=1e-4)
+    assert_close(stats[..., 1], torch.rsqrt(xg.var(-1, unbiased=False) + 1e-5), 1e-4, "rstd")
+    K.gn_silu_fwd(nhwc(q16(rnd(2, 64, 16, 16, seed=5))), torch.ones(64, device=dev()), torch.zeros(64, device=dev()), 8)
+    assert K.last_variant() == "gn_stats+gn_apply"
+
+
 def test_gn_silu_bwd_fused_column_sums():
     """dm_gn_silu_bwd(dx_colsum=...): per-sample channel sums of the written dx, accumulated (+=) in the same pass."""
     from diffusion_model_amd import kernels as K
@@ -545,10 +567,13 @@ def test_batchsum2_cast(K):
 # ------------------------------------------------------------------ GroupNorm folded into the consuming conv
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 20, 36, 128, 64), (2, 12, 12, 64, 128),
                                             (3, 24, 24, 256, 256), (1, 48, 48, 128, 128), (5, 8, 8, 64, 64)])
-def test_groupnorm_folded_into_conv_and_wgrad(K, B, H, W, Cin, Cout):
+def test_groupnorm_folded_into_conv_and_wgrad(K, B, H, W, Cin, Cout, monkeypatch):
     """dm_gn_prepare + dm_conv_args.norm_scale/shift: the conv stages silu(x*scale + shift) itself.  Must equal the
     materialised path (dm_gn_silu_fwd, then the conv on its output) bit for bit -- same expression, same rounding --
-    zero padding included, and the torch statement of GroupNorm -> SiLU -> conv within the bf16 tolerance."""
+    zero padding included, and the torch statement of GroupNorm -> SiLU -> conv within the bf16 tolerance.
+    (Bit equality is against the TWO-PASS dm_gn_silu_fwd, whose statistics kernel dm_gn_prepare shares; the one-pass
+    forward sums in another order and has its own test.)"""
+    monkeypatch.setenv("DM_GN_ONEPASS", "0")
     x = q16(rnd(B, Cin, H, W, seed=1) * 1.5 + 0.3)
     gamma, beta = 1 + 0.1 * rnd(Cin, seed=2), 0.1 * rnd(Cin, seed=3)
     w = rnd(Cout, Cin, 3, 3, seed=4, scale=1.0 / math.sqrt(9 * Cin))
