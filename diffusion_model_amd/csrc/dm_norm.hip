@@ -246,8 +246,13 @@ __global__ __launch_bounds__(OP_THREADS) void gn_onepass_fwd_kernel(const bf16* 
   }
 }
 bool gn_onepass_ok(int HW, int C, int G) {
-  const char* e = getenv("DM_GN_ONEPASS");   // "0": the two-pass kernels (read per call: tests switch it at run time)
-  const bool on = !(e && e[0] == '0');
+  // OPT-IN (DM_GN_ONEPASS=1; read per call: tests switch it at run time).  Alone the kernel beats the two passes (table
+  // below), but its workgroup is a whole CU's registers (1024 threads x 126 VGPRs), so inside the step it cannot share a
+  // CU with the other streams' workgroups and waits for CUs to drain: training step and sampling measured equal at best
+  // (14.52 vs 14.52 ms, 28.2 vs 28.3 img/s), its kernel time in the sampling loop 265 us on average (max 1.36 ms) against
+  // ~100 us for the pair; capped at 64 VGPRs (two workgroups per CU) it spills and loses outright (15.38 vs 15.22 ms).
+  const char* e = getenv("DM_GN_ONEPASS");
+  const bool on = e && e[0] == '1';
   const int cpg = G > 0 ? C / G : 0;
   // 16-channel groups and wider (32-byte pieces and up).  With 8-channel groups (64 channels) a slab is a 16-byte piece
   // of every 128-byte pixel row and the strided stream loses: 64ch@96x96, B=64: 55.7 us against 44.9 us in two passes;

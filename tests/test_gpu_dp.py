@@ -87,8 +87,9 @@ def test_data_parallel_two_ranks_match_gradient_accumulation():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     # Two attempts.  On fresh boxes, about one full-suite run in seven, both ranks (alive, connected over gloo) stopped
-    # reporting; it never happened when this file ran on its own or on a warm box, and a rank that stalls dumps its
-    # Python stack to stderr after 50 s (faulthandler in _worker_body).  The arrangement under test here -- two ranks
+    # reporting; it never happened when this file ran on its own or on a warm box.  A rank that stalls dumps its Python
+    # stack after 50 s (faulthandler in _worker_body); the one stall caught that way had BOTH ranks in GradBuckets.wait()
+    # -> gloo Work.wait(): the gloo all-reduces of the CUDA gradient slices never completed on either rank.  The arrangement under test here -- two ranks
     # time-slicing ONE GPU with gloo staging CUDA tensors through the host -- exists only in this test (RCCL refuses
     # two ranks on one device), so a stall is retried once, loudly, rather than allowed to end the whole GPU suite.
     res = None

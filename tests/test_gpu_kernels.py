@@ -479,12 +479,12 @@ def test_adamw_clip_ema_matches_torch(K):
     assert_close(po, pr2.detach(), 1e-6, "oracle adamw", atol_frac=1e-7)
 
 
-def test_gn_onepass_forward_full_size_and_dispatch(K):
+def test_gn_onepass_forward_full_size_and_dispatch(K, monkeypatch):
     """GroupNorm forward in ONE pass (gn_onepass_fwd_kernel: a (sample, group) slab in the registers of one workgroup)
     at a slab of the maximum size (256 channels @ 48x48: nine pieces per thread), with more than eight samples (two
     rounds of the sample -> XCD placement), a channel-add and an output that is a slice of a wider buffer; 64-channel
     tensors (8-channel groups) must keep the two-pass kernels.  Both against fp32 torch, and against each other."""
-    import os
+    monkeypatch.setenv("DM_GN_ONEPASS", "1")   # opt-in: a whole-CU workgroup does not pay inside the multi-stream step
     B, H, C = 9, 48, 256
     x = q16(rnd(B, C, H, H, seed=1) * 1.3 - 0.2)
     gamma, beta, ca = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, seed=4)
@@ -499,6 +499,11 @@ def test_gn_onepass_forward_full_size_and_dispatch(K):
     assert_close(stats[..., 1], torch.rsqrt(xg.var(-1, unbiased=False) + 1e-5), 1e-4, "rstd")
     K.gn_silu_fwd(nhwc(q16(rnd(2, 64, 16, 16, seed=5))), torch.ones(64, device=dev()), torch.zeros(64, device=dev()), 8)
     assert K.last_variant() == "gn_stats+gn_apply"
+    monkeypatch.delenv("DM_GN_ONEPASS")        # the default: two passes for every width
+    y2, stats2 = K.gn_silu_fwd(nhwc(x), gamma, beta, 8, chan_add=ca)
+    assert K.last_variant() == "gn_stats+gn_apply"
+    assert_close(y2.float(), buf[..., C:].float(), BF, "two-pass vs one-pass")
+    assert_close(stats2, stats, 1e-5, "two-pass vs one-pass statistics", atol_frac=1e-6)
 
 
 def test_gn_silu_bwd_fused_column_sums():
