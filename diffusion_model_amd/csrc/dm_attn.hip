@@ -1545,10 +1545,9 @@ template <bool DROP, int NW, int KT>
 int launch_fused(const AttnParams& p, float* part, hipStream_t st) {
   constexpr int LDS = 4 * 64 * RS + 1024 + 2 * (72 + 64) * 4 + NW * 1024 + NW * 4096;
   auto k = attn_bwd_fused_kernel<DROP, NW, KT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0ull;
+  if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DM_ERR_LAUNCH;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(FB_NK / (NW * KT * 16), p.B * p.H), dim3(NW * 64), LDS, st, p, part);
   DM_LAUNCH_CHECK();

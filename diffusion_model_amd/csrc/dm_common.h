@@ -42,6 +42,17 @@ struct DmVariantName {
 };
 void dm_set_variant(const char* name);
 
+// Per-DEVICE once-flag for hipFuncSetAttribute: a function attribute belongs to the device's code object, so a process
+// that drives several GPUs must set it on each.  `mask` is a function-local static word, one bit per device ordinal.
+static inline bool dm_first_on_device(unsigned long long& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown ordinal: set every time
+  const unsigned long long bit = 1ull << dev;
+  if (__atomic_load_n(&mask, __ATOMIC_RELAXED) & bit) return false;
+  __atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED);   // (the caller sets the attribute right after; idempotent under a race)
+  return true;
+}
+
 static inline int dm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float dm_silu(float x) { return x / (1.0f + __expf(-x)); }

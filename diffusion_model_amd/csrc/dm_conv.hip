@@ -466,11 +466,10 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   constexpr int LDS = A_BYTES + 2 * KSPS * NT * 1024;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU must fit in 160 KiB of LDS");
   auto k = conv_mfma_kernel<TH, TW, S, PITCH, STRIDE, NT, MODE, NORM>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0ull;
+  if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
-    attr_set = true;
   }
   dim3 grid;
   if (MODE == MODE_GEMM) grid = dim3((unsigned)((p.M + TH * TW - 1) / (TH * TW)), (unsigned)(p.Cout / (16 * NT)));
@@ -711,11 +710,10 @@ int launch_conv_ws(const ConvParams& p0, hipStream_t st) {
   constexpr int LDS = 10 * ((TW == 24) ? 32 : TW + 2) * 160 + 2 * 2 * NT * 1024;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
   auto k = conv_ws_kernel<NT, MODE, TW>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0ull;
+  if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
-    attr_set = true;
   }
   ConvParams p = p0;
   const long ntiles = (long)p.B * p.tiles_h * p.tiles_w;
@@ -848,11 +846,10 @@ int launch_gemm_stream_v(const ConvParams& p, hipStream_t st) {
   constexpr int LDS = NKS * NT * 1024;
   static_assert(LDS <= 64 * 1024, "two workgroups per CU");
   auto k = gemm_stream_kernel<MT, NT, NKS, WIDE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0ull;
+  if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
-    attr_set = true;
   }
   const int ntiles = (int)((p.M + 16 * MT - 1) / (16 * MT));  // wave tiles
   const int gy = p.Cout / (16 * NT);

@@ -419,11 +419,10 @@ int launch_wgrad(const WgradParams& p, const Plan& pl, hipStream_t st) {
   constexpr int LDS = X_BYTES + TH * TW * DYS;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
   auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS, NORM>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devs = 0ull;
+  if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
-    attr_set = true;
   }
   static const DmVariantName vn(NORM ? "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d,NORM>" : "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>",
                                 TH, TW, S, MODE, TAPS);

@@ -68,7 +68,22 @@ def set_dropout_counter(counter: Optional[torch.Tensor]) -> None:
     (dm_set_dropout_counter): int32/uint32 tensor of one element that the caller keeps alive."""
     if counter is not None and not (counter.is_cuda and counter.numel() == 1 and counter.element_size() == 4):
         raise ValueError("dropout counter: need a one-element 32-bit CUDA tensor")
+    if counter is not None and _DROP_COUNTER[0] is not None and _DROP_COUNTER[0] != counter.data_ptr():
+        raise RuntimeError("dropout counter: another counter is registered (one graph-replaying Trainer per process; "
+                           "call disable_graph() on the other one first)")
     check(_lib.lib().dm_set_dropout_counter(_p(counter)), "dm_set_dropout_counter")
+    _DROP_COUNTER[0] = None if counter is None else counter.data_ptr()
+
+
+_DROP_COUNTER = [None]   # address registered with the library (process-global state of libdm_hip.so: INTEGRATION.md)
+
+
+def release_dropout_counter(ptr: int) -> None:
+    """Unregister the counter at ``ptr`` if it is still the registered one (weakref.finalize of its owner: a Trainer
+    dropped without disable_graph() must not leave the library pointing at freed memory)."""
+    if _DROP_COUNTER[0] == ptr and _lib is not None:
+        _lib.lib().dm_set_dropout_counter(None)
+        _DROP_COUNTER[0] = None
 
 
 def bump_dropout_counter(counter: torch.Tensor) -> None:
@@ -78,6 +93,21 @@ def bump_dropout_counter(counter: torch.Tensor) -> None:
 # --------------------------------------------------------------------------- workspace
 _WS = {}
 _WS_RETIRED = []   # outgrown side-stream buffers, kept alive until join_side() (see workspace())
+# HIP-graph replay bakes workspace ADDRESSES into the captured kernels.  While a graph is live (Trainer.enable_graph
+# pins, disable_graph unpins) an outgrown buffer is therefore never released: it moves here, so a later eager call with
+# a larger shape gets a new buffer while the graph keeps replaying into memory that is still ours.
+_WS_PIN_COUNT = [0]
+_WS_PINNED_KEEP = []
+
+
+def pin_workspaces() -> None:
+    _WS_PIN_COUNT[0] += 1
+
+
+def unpin_workspaces() -> None:
+    _WS_PIN_COUNT[0] = max(0, _WS_PIN_COUNT[0] - 1)
+    if _WS_PIN_COUNT[0] == 0:
+        _WS_PINNED_KEEP.clear()
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -93,7 +123,9 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     key = (device.index if isinstance(device, torch.device) else torch.device(device).index, _stream())
     cur = _WS.get(key)
     if cur is None or cur.numel() < nbytes:
-        if cur is not None and forced is not None:
+        if cur is not None and _WS_PIN_COUNT[0] > 0:
+            _WS_PINNED_KEEP.append(cur)
+        elif cur is not None and forced is not None:
             _WS_RETIRED.append(cur)
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = cur
@@ -294,6 +326,7 @@ def join_side(device=None) -> None:
 # to_q / to_k projections and the log-sum-exp feed nothing the main chain needs before the backward pass).
 _AUX = {}
 _AUX_DIRTY = set()
+_AUX_JOIN_EV = {}   # per device: the event call_on_side records on the auxiliary stream (aux -> side join)
 
 
 def aux_stream(device):
@@ -373,9 +406,22 @@ def call_on_side(device, fn) -> None:
     side, ev = _side_stream(dev)
     ev.record()
     side.wait_event(ev)
+    # ORDERING RULE: what fn() consumes may have been produced on THREE streams -- the current one
+    # (fork above), the weight-gradient stream itself (in order) and the auxiliary stream, which carries the one-token
+    # attention backward branch (to_out / to_v / to_q / to_k / qkv gradients, written inline there when DM_SIDE_WGRAD=0).
+    # The auxiliary stream is joined explicitly: the side stream waits for everything enqueued on it so far, whether
+    # or not a weight gradient happened to fork from it.
+    key = dev.index or 0
+    if key in _AUX_DIRTY:
+        aux, _ = aux_stream(dev)
+        jev = _AUX_JOIN_EV.get(key)
+        if jev is None:
+            jev = _AUX_JOIN_EV[key] = torch.cuda.Event()
+        jev.record(aux)
+        side.wait_event(jev)
     with torch.cuda.stream(side):
         fn()
-    _SIDE_DIRTY.add(dev.index or 0)
+    _SIDE_DIRTY.add(key)
 
 
 # --------------------------------------------------------------------------- norm
@@ -471,7 +517,7 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
     a.delta = _p(delta)
     nb = _lib.lib().dm_attn_bwd_workspace_bytes(B, heads, Nq, Nk, Cc // heads)
-    if nb > 0 and single_pass:   # single-pass backward: two fp32 partial copies of dq
+    if nb > 0 and single_pass:   # single-pass backward: one fp32 dq partial per key split
         ws = workspace(nb, q.device)
         a.workspace, a.ws_bytes = _p(ws), ws.numel()
     check(_lib.lib().dm_attn_bwd(C.byref(a), _stream()), "dm_attn_bwd")

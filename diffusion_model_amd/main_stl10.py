@@ -120,7 +120,7 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
 
     n_batches = len(train_loader)
     if distributed and world > 1:   # a custom train_loader may be ragged across ranks: every rank runs the common prefix
-        nb = torch.tensor([n_batches], device=device)
+        nb = torch.tensor([n_batches], device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(nb, op=dist.ReduceOp.MIN)
         n_batches = int(nb.item())
     accum = max(1, VIRTUAL_BATCH_SIZE_MULTIPLIER)
@@ -162,8 +162,12 @@ def train(checkpoint_path=None, clip_table_path: str = CLIP_TABLE_PATH, *, train
         log(f"Epoch {epoch + 1} | Loss {float(sum_loss.item()) / max(1, n_batches):.5f}")
         if monitor_dir is not None and (epoch + 1) % max(1, monitor_every) == 0 and utils.CONTEXT_TABLE is not None:
             from . import visualization as V
+            # EVERY rank draws the monitoring batch: a shuffling loader advances its epoch-order generator per
+            # iter(), and the ranks' generators must stay in lockstep or the next epoch's order[rank::world] shards
+            # no longer partition the epoch (tests/test_cpu_data.py).  Only rank 0 samples from it and writes files.
+            mon_batch = next(iter(train_loader))
             if rank == 0:   # single-rank jobs: the other ranks would write the same files
-                V.reconstruct_sweep(ema.module, scheduler, train_loader, epoch + 1, device, NUM_TIME_STEPS, SAMPLING_ETA,
+                V.reconstruct_sweep(ema.module, scheduler, [mon_batch], epoch + 1, device, NUM_TIME_STEPS, SAMPLING_ETA,
                                     None, monitor_dir, t_list=[700, 500, 300, 200], guidance_scale=CFG_SCALE)
                 V.generate_denoise_collage(ema.module, scheduler, epoch + 1, 1, [499, 400, 300, 200, 100, 50, 15, 0],
                                            device, NUM_TIME_STEPS, SAMPLING_ETA, None, monitor_dir,

@@ -98,9 +98,35 @@ class GradBuckets:
         # instead of one per stage -- fewer collective launches, no overlap with the backward (measurement switch)
         self.single = os.environ.get("DM_DP_BUCKETS", "") == "1"
         self.last_stage = stage_names[-1][0]
+        # Transport.  RCCL ("nccl") reduces device memory in place on its own stream.  A host-side backend (gloo) cannot
+        # touch device memory: instead of torch's gloo-CUDA shim (pinned staging on pool streams that gloo WORKER
+        # THREADS synchronise and copy back from, concurrently with this thread's launches) the staging is done here,
+        # in stream order, by this thread: D2H copy of the bucket on the issuing stream + an event; wait() synchronises
+        # the event, reduces the HOST tensor and copies it back on the current stream.
+        self.host_staged = bool(fp.grad.is_cuda and dist.is_initialized() and dist.get_backend(process_group) != "nccl")
+        self.host = torch.empty(fp.total, dtype=torch.float32, pin_memory=True) if self.host_staged else None
+        self.issued = self.completed = 0      # collectives issued / finished (stall diagnostics: describe())
+        self.stage_events = []                # (stage, event recorded on the issuing stream right behind the launch)
+
+    def describe(self) -> str:
+        """One line for a stall dump: how many collectives were issued / completed and which stage events have fired."""
+        ev = ", ".join("%s:%s" % (s, "done" if e.query() else "PENDING") for s, e in self.stage_events)
+        return "collectives issued %d completed %d; stage events [%s]" % (self.issued, self.completed, ev)
 
     def launch(self, stage: str) -> None:
         if self.world == 1 and not self.force:   # (force: rehearse the collective path on one rank, bench --rehearse-dp)
+            return
+        if self.host_staged:
+            if self.single and stage != self.last_stage:
+                return
+            ranges = [(0, self.fp.total)] if self.single else self.stage_ranges[stage]
+            for a, b in ranges:
+                self.host[a:b].copy_(self.fp.grad[a:b], non_blocking=True)   # on the issuing (weight-gradient) stream
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((ranges, ev))
+            self.stage_events.append((stage, ev))
+            self.issued += len(ranges)
             return
         # DM_DP_SYNC=1 (measurement switch): blocking-style collectives.  They are issued with the weight-gradient
         # stream current (unet hook -> kernels.call_on_side), so "blocking" orders that stream behind them, not the host
@@ -109,18 +135,36 @@ class GradBuckets:
         if self.single:
             if stage == self.last_stage:
                 w = self.dist.all_reduce(self.fp.grad, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=not sync)
+                self.issued += 1
                 if not sync:
                     self.pending.append(w)
             return
         for a, b in self.stage_ranges[stage]:
             w = self.dist.all_reduce(self.fp.grad[a:b], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=not sync)
+            self.issued += 1
             if not sync:
                 self.pending.append(w)
+        if torch.cuda.is_available() and self.fp.grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stage_events.append((stage, ev))
 
     def wait(self) -> None:
+        if self.host_staged:
+            for ranges, ev in self.pending:
+                ev.synchronize()                      # the bucket's bytes are in pinned host memory
+                for a, b in ranges:
+                    self.dist.all_reduce(self.host[a:b], op=self.dist.ReduceOp.SUM, group=self.pg)   # host tensor, blocking
+                    self.fp.grad[a:b].copy_(self.host[a:b], non_blocking=True)   # current stream; its producers are done (event)
+                    self.completed += 1
+            self.pending = []
+            self.stage_events = []
+            return
         for w in self.pending:
             w.wait()
+            self.completed += 1
         self.pending = []
+        self.stage_events = []
 
 
 def unet_stage_names(model) -> List[Tuple[str, List[str]]]:
@@ -189,8 +233,15 @@ class Trainer:
         if self.world <= 1:
             return
         import torch.distributed as dist
+        staged = self.buckets is not None and self.buckets.host_staged   # host-side backend: stage here (GradBuckets)
         for buf in (self.fp.flat, self.ema_flat, self.m, self.v):
-            if buf is not None:
+            if buf is None:
+                continue
+            if staged:
+                h = buf.cpu()
+                dist.broadcast(h, src=src, group=self.pg)
+                buf.copy_(h)
+            else:
                 dist.broadcast(buf, src=src, group=self.pg)
         invalidate_packed_weights()
 
@@ -237,8 +288,13 @@ class Trainer:
         if self.micro != 0:
             raise RuntimeError("enable_graph: call at an accumulation boundary")
         dev = x.device
+        if self._graph is not None:
+            self.disable_graph()
         self._gctr = torch.zeros(1, dtype=torch.int32, device=dev)
-        K.set_dropout_counter(self._gctr)
+        K.set_dropout_counter(self._gctr)   # raises if another live Trainer holds the registration
+        import weakref
+        self._gfin = weakref.finalize(self, K.release_dropout_counter, self._gctr.data_ptr())
+        K.pin_workspaces()                  # replay bakes workspace addresses in: outgrown buffers stay alive (kernels.workspace)
         self._gin = (x.clone(), None if context is None else context.clone(), t.clone(), e.clone())
         self.model._bwd_hook = None
         side = torch.cuda.Stream(device=dev)
@@ -260,10 +316,13 @@ class Trainer:
         self._graph = graph
 
     def disable_graph(self) -> None:
+        if self._gctr is not None:
+            K.release_dropout_counter(self._gctr.data_ptr())
+            self._gfin.detach()
+            K.unpin_workspaces()
         self._graph = None
         self._gin = self._gloss = None
         self._gctr = None
-        K.set_dropout_counter(None)
 
     def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, *,
                    step_now: Optional[bool] = None, check_finite: bool = False) -> torch.Tensor:
@@ -304,6 +363,8 @@ class Trainer:
                 # data parallel: skip on ALL ranks or on none -- a rank that returned alone would never launch its
                 # bucket all-reduces or the optimizer step, and the others would wait for it forever
                 flag = ok.to(torch.int32)
+                if self.buckets.host_staged:
+                    flag = flag.cpu()
                 self.buckets.dist.all_reduce(flag, op=self.buckets.dist.ReduceOp.MIN, group=self.pg)
                 ok = flag
             if not bool(ok.item()):

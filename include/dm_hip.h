@@ -194,7 +194,8 @@ typedef struct dm_attn_args {
  * dm_cross1_fwd) may pass o = NULL (forward).  Any other NULL is DM_ERR_ARG. */
 int dm_attn_fwd(const dm_attn_args* args, dm_stream_t stream);
 int dm_attn_bwd(const dm_attn_args* args, dm_stream_t stream);
-/* Scratch the single-pass backward wants for this shape (two fp32 partial copies of dq), or 0 when the shape has none. */
+/* Scratch the single-pass backward wants for this shape -- one fp32 partial copy of dq per key split (currently 4; the
+ * count is an implementation detail: ALWAYS size the buffer with this function) -- or 0 when the shape has none. */
 long dm_attn_bwd_workspace_bytes(int B, int heads, int Nq, int Nk, int hd);
 
 /* One-token cross-attention, output side, as one streaming pass.  Replaces, for a single context token (the CLIP-table

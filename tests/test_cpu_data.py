@@ -84,6 +84,28 @@ def test_loader_epochs_shuffle_and_rank_shards(tmp_path):
     assert sorted(sum(per_rank, [])) == list(range(40))
 
 
+def test_rank_loaders_stay_in_lockstep_across_monitoring_draws(tmp_path):
+    """main_stl10.train() pulls one monitoring batch per epoch with next(iter(loader)).  iter() advances the loader's
+    epoch-order generator, so the draw must happen on EVERY rank (train() does; only rank 0 uses the batch): then the next
+    epoch's order[rank::world] shards still partition the epoch.  A draw on one rank alone breaks the partition."""
+    write_split(tmp_path, 40, seed=6)
+    ref = normalize_uint8(torch.from_numpy(read_stl10_binary(str(tmp_path), "train")[0]))
+    key = lambda r: tuple(r[:, 0, 0].tolist()) + tuple(r[:, 5, 7].tolist())  # noqa: E731
+    index = {key(r): i for i, r in enumerate(ref)}
+    mk = lambda r: STL10Loader(str(tmp_path), "train", batch_size=5, shuffle=True, seed=3, rank=r, world_size=2)  # noqa: E731
+    epoch = lambda ld: [index[key(xi)] for x, _ in ld for xi in x]  # noqa: E731
+    a, b = mk(0), mk(1)
+    for _ in range(2):     # two epochs, each followed by the monitoring draw on both ranks
+        ea, eb = epoch(a), epoch(b)
+        assert sorted(ea + eb) == list(range(40))
+        next(iter(a)); next(iter(b))
+    assert sorted(epoch(a) + epoch(b)) == list(range(40))
+    a, b = mk(0), mk(1)
+    epoch(a), epoch(b)
+    next(iter(a))          # rank 0 alone (what train() must not do): the generators part ways
+    assert sorted(epoch(a) + epoch(b)) != list(range(40))
+
+
 def test_loader_exact_batches_unshuffled(tmp_path):
     imgs, labels = write_split(tmp_path, 10, seed=1)
     ld = STL10Loader(str(tmp_path), "train", batch_size=4, shuffle=False, drop_last=True)

@@ -1,7 +1,10 @@
 """configs[2] on real kernels: the data-parallel training step with TWO ranks.  One GPU box has one GPU and RCCL refuses
-two ranks on one device, so the ranks share cuda:0 and exchange gradients over gloo (CUDA tensors staged through the host)
--- the Trainer, the bucket hook on the weight-gradient side stream, the broadcast of the replicas and the fused
-clip + AdamW + EMA are exactly the N > 1 code path; only the transport differs from RCCL."""
+two ranks on one device, so the ranks share cuda:0 and exchange gradients over gloo -- the Trainer, the bucket hook on
+the weight-gradient side stream (ordered behind the main AND the auxiliary stream, kernels.call_on_side), the broadcast
+of the replicas and the fused clip + AdamW + EMA are exactly the N > 1 code path; only the transport differs from RCCL:
+GradBuckets stages each bucket to pinned host memory itself, in stream order (trainer.GradBuckets.host_staged), and
+reduces the HOST tensor -- torch's gloo-CUDA shim with its worker-thread stream synchronisation is not involved.
+One attempt: a stall fails the test, with the ranks' Python stacks and the buckets' stage-event / stream state."""
 import os
 import tempfile
 import sys
@@ -33,22 +36,48 @@ def _make(seed):
     return m.to("cuda:0").train()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, side_wgrad):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, side_wgrad)
     except BaseException:   # report instead of leaving the peer (and the parent) waiting
         import traceback
         q.put({"rank": rank, "error": traceback.format_exc()})
         raise
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, side_wgrad):
     import datetime
     import faulthandler
+    import threading
     import torch.distributed as dist
-    # a rank that hangs says where, before the parent gives up (the parent quotes the file in its message)
+    # a rank that hangs says where, before the parent gives up (the parent quotes the file in its message): its Python
+    # stack, and -- from a watchdog thread -- whether the GPU work ahead of each bucket has drained (stage events, the
+    # three streams) and how many collectives were issued / completed: "the streams never drain" and "the host exchange
+    # never completes" are different bugs
     _trace = open(os.path.join(tempfile.gettempdir(), "dm_dp_rank%d_%d.trace" % (rank, port)), "w")
     faulthandler.dump_traceback_later(50, exit=False, file=_trace)
+    state = {}
+
+    def _watchdog():
+        import time
+        time.sleep(48)
+        try:
+            from diffusion_model_amd import kernels as K
+            tr = state.get("tr")
+            lines = ["rank %d watchdog" % rank]
+            if tr is not None and tr.buckets is not None:
+                lines.append(tr.buckets.describe())
+            for name, tab in (("side", K._SIDE), ("aux", K._AUX)):
+                for key, (st, _) in tab.items():
+                    lines.append("%s stream dev %s idle=%s" % (name, key, st.query()))
+            lines.append("main stream idle=%s" % torch.cuda.current_stream(0).query())
+            _trace.write("\n".join(lines) + "\n")
+            _trace.flush()
+        except Exception as exc:   # diagnostics must not mask the stall itself
+            _trace.write("watchdog failed: %r\n" % (exc,))
+            _trace.flush()
+
+    threading.Thread(target=_watchdog, daemon=True).start()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     torch.cuda.set_device(0)
@@ -57,9 +86,12 @@ def _worker_body(rank, world, port, q):
         from diffusion_model_amd import kernels as K
         from diffusion_model_amd.trainer import Trainer
         from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+        K.SIDE_WGRAD = bool(side_wgrad)               # False = DM_SIDE_WGRAD=0: weight gradients inline on the main / auxiliary stream
         model = _make(10 + rank)                      # different replicas on purpose: rank 0's must win
         tr = Trainer(model, DDPM_beta_t_cosine_scheduler(500), lr=1e-3, clip=1.0, accum=1, total_steps=100,
                      low_t_weight=0.01, distributed=True)
+        state["tr"] = tr
+        assert tr.buckets.host_staged
         p0 = tr.fp.flat.detach().cpu().clone()
         tr.defer_optimizer = True
         dev = torch.device("cuda:0")
@@ -80,45 +112,34 @@ def _worker_body(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_two_ranks_match_gradient_accumulation():
+@pytest.mark.parametrize("side_wgrad", [True, False], ids=["side_wgrad", "inline_wgrad"])
+def test_data_parallel_two_ranks_match_gradient_accumulation(side_wgrad):
     import queue as _queue
     import socket
-    import warnings
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    # Two attempts.  On fresh boxes, about one full-suite run in seven, both ranks (alive, connected over gloo) stopped
-    # reporting; it never happened when this file ran on its own or on a warm box.  A rank that stalls dumps its Python
-    # stack after 50 s (faulthandler in _worker_body); the one stall caught that way had BOTH ranks in GradBuckets.wait()
-    # -> gloo Work.wait(): the gloo all-reduces of the CUDA gradient slices never completed on either rank.  The arrangement under test here -- two ranks
-    # time-slicing ONE GPU with gloo staging CUDA tensors through the host -- exists only in this test (RCCL refuses
-    # two ranks on one device), so a stall is retried once, loudly, rather than allowed to end the whole GPU suite.
-    res = None
-    for attempt in range(2):
-        q = ctx.Queue()
-        with socket.socket() as sk:          # a port that is free right now
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    q = ctx.Queue()
+    with socket.socket() as sk:          # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, side_wgrad)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=90) for _ in procs]
+    except _queue.Empty:
+        codes = [p.exitcode for p in procs]
+        for r in range(2):
+            try:
+                with open(os.path.join(tempfile.gettempdir(), "dm_dp_rank%d_%d.trace" % (r, port))) as f:
+                    codes.append("rank %d: %s" % (r, f.read()[-2500:]))
+            except OSError:
+                pass
         for p in procs:
-            p.start()
-        try:
-            res = [q.get(timeout=70) for _ in procs]
-            break
-        except _queue.Empty:
-            codes = [p.exitcode for p in procs]
-            for r in range(2):
-                try:
-                    with open(os.path.join(tempfile.gettempdir(), "dm_dp_rank%d_%d.trace" % (r, port))) as f:
-                        codes.append("rank %d stack: %s" % (r, f.read()[-1500:]))
-                except OSError:
-                    pass
-            for p in procs:
-                p.kill()
-            for p in procs:
-                p.join(20)
-            if attempt == 1:
-                raise AssertionError("a data-parallel rank did not report within 70 s, twice (exit codes %s)" % codes)
-            warnings.warn("test_gpu_dp: the two ranks stalled (exit codes %s); retrying once" % codes)
+            p.kill()
+        for p in procs:
+            p.join(20)
+        raise AssertionError("a data-parallel rank did not report within 90 s (exit codes %s)" % codes)
     for r in res:
         assert "error" not in r, r["error"]
     res = sorted(res, key=lambda r: r["rank"])
@@ -134,6 +155,7 @@ def test_data_parallel_two_ranks_match_gradient_accumulation():
     # ... and the reduced gradient is the gradient-accumulation gradient of one process over both ranks' batches
     from diffusion_model_amd.trainer import Trainer
     from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+    from diffusion_model_amd import kernels as K
     model = _make(10)
     tr = Trainer(model, DDPM_beta_t_cosine_scheduler(500), lr=1e-3, clip=1.0, accum=2, total_steps=100, low_t_weight=0.01)
     assert torch.equal(tr.fp.flat.detach().cpu(), r0["p0"])
@@ -142,7 +164,6 @@ def test_data_parallel_two_ranks_match_gradient_accumulation():
     for step in range(2):
         for rank in range(2):
             tr.micro_step(*[v.to(dev) for v in _batch(100 + 10 * step + rank)])
-        from diffusion_model_amd import kernels as K
         K.join_side(dev)
         torch.cuda.synchronize()
         g = tr.fp.grad.detach().cpu()
