@@ -32,7 +32,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--sample-images", type=int, default=88, help="CFG samples per GPU (88 x 8 GPUs = 11 labels x 64 = configs[3];  0 = skip)")
+    ap.add_argument("--sample-images", type=int, default=-1,
+                    help="CFG samples per GPU; default 704 / N = configs[3] (11 labels x 64 samples, batch-sharded); 0 = skip")
+    ap.add_argument("--sample-chunk", type=int, default=88, help="images per sampler launch (UNet batch = 2 x this)")
     ap.add_argument("--sample-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -55,6 +57,31 @@ def synth_batch(B, rank, dev, table, scheduler):
     e = torch.randn(B, 3, 96, 96, generator=g).to(dev)
     ctx = table[labels].to(dev).contiguous()
     return x, ctx, t, e
+
+
+class StepData:
+    """The per-micro-step input statements of the reference loop (main_stl10.py:453-469), run INSIDE the timed steps:
+    label drop w.p. 0.2 -> UNCOND_ID, t ~ randint(0, 500) drawn on the host as in the reference (:458), e ~ randn_like(x)
+    on the device, context = CONTEXT_TABLE[labels_dropped].  The images and labels of the rank's two batches are resident
+    in HBM (the DataLoader's job, outside the hot path)."""
+
+    def __init__(self, B, rank, dev, table):
+        self.dev, self.table = dev, table.to(dev)
+        self.batches = []
+        for i in range(2):
+            g = torch.Generator(device="cpu").manual_seed(1234 + 2 * rank + i)
+            x = torch.clamp(torch.randn(B, 3, 96, 96, generator=g) * 0.5, -1, 1).to(dev)
+            self.batches.append((x, torch.randint(0, 10, (B,), generator=g).to(dev)))
+        self.g_cpu = torch.Generator().manual_seed(777 + rank)
+        self.g_dev = torch.Generator(device=dev).manual_seed(778 + rank)
+
+    def draw(self, i):
+        x, labels = self.batches[i]
+        drop = torch.rand(labels.shape[0], device=self.dev, generator=self.g_dev) < 0.2
+        labels_dropped = torch.where(drop, torch.full_like(labels, 10), labels)
+        t = torch.randint(0, 500, (x.shape[0],), generator=self.g_cpu).to(self.dev, non_blocking=True)
+        e = torch.randn(x.shape, device=self.dev, dtype=x.dtype, generator=self.g_dev)
+        return x, self.table[labels_dropped], t, e
 
 
 def build_model(dropout, dev):
@@ -208,6 +235,94 @@ def time_conv_kernel(B, dev, H=48, cin=128, cout=128, mode=2, reps=20):
     return s.elapsed_time(e) * 1e-3 / reps, 2.0 * B * Ho * Ho * cout * cin * 9, variant
 
 
+PEAK_HBM = 8.0e12        # MI355X HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel reaches)
+# VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle (a wave64 instruction occupies its SIMD for 4 cycles) at 2.4 GHz
+PEAK_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
+
+
+def _timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps
+
+
+def hbm_rooflines(dev, B):
+    """Live HIP-event timing (back to back, current stream) of the HBM-bound kernels of the step at their B-per-GPU shapes,
+    against ALGORITHMIC bytes (GroupNorm+SiLU 4 B/elem forward, 6 B/elem backward at bf16; fused optimizer 32
+    B/param moved by adamw_ema_step itself (+4 for the norm pass = the survey's 36); sampler step 20 B/elem) and the
+    8 TB/s HBM peak."""
+    from diffusion_model_amd import kernels as K
+    out = []
+
+    def row(name, sec, nbytes):
+        out.append({"kernel": name, "avg_launch_us": sec * 1e6, "algorithmic_bytes": nbytes,
+                    "achieved": nbytes / sec / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / sec / PEAK_HBM})
+
+    for H, C in ((96, 64), (48, 128), (24, 256), (48, 256)):   # the ResBlock norm shapes of the STL10 UNet
+        x = torch.randn(B, H, H, C, device=dev).to(torch.bfloat16)
+        dy = torch.randn(B, H, H, C, device=dev).to(torch.bfloat16)
+        gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        _, stats = K.gn_silu_fwd(x, gam, bet, 8, out=y)
+        n = x.numel()
+        row(f"gn_silu_fwd {C}ch@{H}x{H}", _timeit(lambda: K.gn_silu_fwd(x, gam, bet, 8, out=y)), 4 * n)
+        row(f"gn_silu_bwd {C}ch@{H}x{H}", _timeit(lambda: K.gn_silu_bwd(x, dy, gam, bet, stats, 8, dg, db, out=dx)), 6 * n)
+        del x, dy, y, dx
+    N = 4177539 // 4 * 4 + 4
+    p, g, m, v, ema = (torch.randn(N, device=dev) * 0.01 for _ in range(5))
+    v = v.abs()
+    norm = torch.zeros(2, device=dev)
+    row("grad_norm_clipcoef 4.18 M params", _timeit(lambda: K.grad_norm_clipcoef(g, 1.0, out=norm)), 4 * N)
+    row("adamw_ema_step 4.18 M params",
+        _timeit(lambda: K.adamw_ema_step(p, g, m, v, ema, norm, lr=5e-5, beta1=0.9, beta2=0.99, eps=1e-8, wd=1e-4, step=3,
+                                         ema_decay=0.995)), 32 * N)
+    S = 88
+    z, vu, vc, nz = (torch.randn(S, 3, 96, 96, device=dev) for _ in range(4))
+    coef = torch.rand(S, 8, device=dev)
+    zo = torch.empty_like(z)
+    row(f"cfg_ddpm_step S={S}", _timeit(lambda: K.cfg_ddpm_step(z, vu, vc, nz, coef, out=zo)), 20 * z.numel())
+    x, e = torch.randn(B, 3, 96, 96, device=dev), torch.randn(B, 3, 96, 96, device=dev)
+    ab = torch.rand(B, device=dev)
+    row(f"qsample_vtarget B={B}", _timeit(lambda: K.qsample_vtarget(x, e, ab)), 16 * x.numel())
+    return out
+
+
+def attention_roofline(dev, B, p):
+    """The L2 self-attention (N = 2304 tokens, 8 heads x 16) forward and backward: with 16-dimensional heads the flash
+    loop spends 64 MFMA flop per score element but ~5.8 VALU instructions (one of them v_exp_f32 at quarter rate: 8.8 issue
+    slots), so the kernel's roofline is VALU ISSUE, not the MFMA pipe (profiles/r02_pmc_attention.txt: 380 M VALU against
+    32 M MFMA instructions).  Both fractions are reported; `bound` names the one that binds."""
+    from diffusion_model_amd import kernels as K
+    N, C, heads = 2304, 128, 8
+    g = torch.Generator().manual_seed(0)
+    q, k, v, d_o = ((torch.randn(B, N, C, generator=g) * 0.7).to(dev).to(torch.bfloat16) for _ in range(4))
+    o, lse = K.attn_fwd(q, k, v, heads, drop_p=p, drop_seed=5)
+    tf = _timeit(lambda: K.attn_fwd(q, k, v, heads, drop_p=p, drop_seed=5), reps=10, warm=2)
+    tb = _timeit(lambda: K.attn_bwd(q, k, v, o, lse, d_o, heads, drop_p=p, drop_seed=5), reps=10, warm=2)
+    scores = float(B) * heads * N * N
+    flop_f, flop_b = 4.0 * scores * (C // heads), 10.0 * scores * (C // heads)
+    # issue slots per score element (DESIGN section 9): forward 4.8 plain VALU + one quarter-rate v_exp_f32; backward 28 VALU
+    # instructions per 16x16 tile of which 4 are v_exp_f32: (24 + 4 * 4) wave instructions x 64 lanes / 256 scores
+    slots_f, slots_b = 8.8, (24 + 4 * 4) * 64 / 256.0
+    return [{"kernel": "attn_fwd L2 self-attention N=2304 hd=16, B=%d, dropout %.1f" % (B, p), "bound": "valu",
+             "avg_launch_us": tf * 1e6, "valu_issue_slots_per_score": slots_f,
+             "achieved": scores * slots_f / tf / 1e12, "peak": PEAK_VALU_LANE_OPS / 1e12, "unit": "T lane-ops/s",
+             "frac": scores * slots_f / tf / PEAK_VALU_LANE_OPS,
+             "mfma_tflops": flop_f / tf / 1e12, "mfma_frac": flop_f / tf / PEAK_BF16},
+            {"kernel": "attn_bwd (single pass) same shape", "bound": "valu", "avg_launch_us": tb * 1e6,
+             "valu_issue_slots_per_score": slots_b, "achieved": scores * slots_b / tb / 1e12,
+             "peak": PEAK_VALU_LANE_OPS / 1e12, "unit": "T lane-ops/s", "frac": scores * slots_b / tb / PEAK_VALU_LANE_OPS,
+             "mfma_tflops": flop_b / tb / 1e12, "mfma_frac": flop_b / tb / PEAK_BF16,
+             "note": "28 VALU instructions (4 v_exp_f32) + 5 MFMAs per 16x16 score tile through one issue port"}]
+
+
 def cpu_baseline():
     """The oracle (CPU fp32 restatement of the reference, oracle/) timed on this box's host cores, SURVEY.md 8(d):
     config C1 = B=8, 96x96, CLIP context, v-loss with low-t weighting, clip 1.0, AdamW, same synthetic recipe --
@@ -343,12 +458,13 @@ def main():
                  distributed=world > 1 or (a.rehearse_dp and os.environ.get("DM_REHEARSE_MODE", "") != "pgonly"))
     if a.rehearse_dp and tr.buckets is not None:
         tr.buckets.force = os.environ.get("DM_REHEARSE_NOFORCE", "") != "1"   # (=1: process group and hooks, no collective)
-    batches = [synth_batch(a.batch, rank * 2 + i, dev, table, sched) for i in range(2)]
+    data = StepData(a.batch, rank, dev, table)
+    batches = [synth_batch(a.batch, rank * 2 + i, dev, table, sched) for i in range(2)]   # (--graph: static inputs)
 
     def opt_step():
         loss = None
-        for b in batches:
-            loss = tr.micro_step(*b)
+        for i in range(2):
+            loss = tr.micro_step(*data.draw(i))   # t, e, label drop and context drawn per micro-step, as the reference does
         return loss
 
     def barrier():
@@ -442,16 +558,30 @@ def main():
 
     # ---------------- sampling leg (batch-sharded, no collective in the loop)
     sampling = None
-    if a.sample_images > 0:
-        S = a.sample_images
+    from diffusion_model_amd.sampler import shard_bounds
+    TOTAL = 704                                    # configs[3]: 11 labels x 64 samples
+    if a.sample_images < 0:
+        lo, hi = shard_bounds(TOTAL, rank, world)  # batch-sharded over the ranks, contiguous shards (sampler.sample_sharded)
+    else:
+        lo, hi = rank * a.sample_images, (rank + 1) * a.sample_images
+    S = hi - lo
+    n_images = TOTAL if a.sample_images < 0 else a.sample_images * world
+    if n_images > 0:
         smp = CFGSampler(ema.module, sched, table, uncond_id=10)
         gz = torch.Generator(device="cpu").manual_seed(42 + rank)
         z = torch.randn(S, 3, 96, 96, generator=gz).to(dev)
-        labels = (torch.arange(S) + rank * S) % 11
-        smp.sample(z[:S], labels, 6.0, 1.0, num_time_steps=500, t_stop=497)  # warm-up: 3 steps
+        labels = torch.arange(lo, hi) % 11
+        chunk = max(1, a.sample_chunk)
+
+        def chunks(fn):   # the shard in launches of `chunk` images (UNet batch 2 x chunk); no collective anywhere
+            return torch.cat([fn(z[c:c + chunk], labels[c:c + chunk]) for c in range(0, S, chunk)]) if S else z
+
+        wl = min(S, chunk)
+        if S:
+            smp.sample(z[:wl], labels[:wl], 6.0, 1.0, num_time_steps=500, t_stop=497)  # warm-up: 3 steps
         barrier()
         t1 = time.perf_counter()
-        x0 = smp.sample(z, labels, 6.0, 1.0, num_time_steps=a.sample_steps)
+        x0 = chunks(lambda zz, ll: smp.sample(zz, ll, 6.0, 1.0, num_time_steps=a.sample_steps))
         barrier()
         ds = time.perf_counter() - t1
         if world > 1:
@@ -459,10 +589,13 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ds = float(tt.item())
         ok = bool(torch.isfinite(x0).all().item())
-        sampling = {"metric": "500-step CFG sample img/s", "value": S * world / ds, "unit": "img/s",
-                    "images": S * world, "steps": a.sample_steps, "seconds": ds, "guidance": 6.0, "eta": 1.0,
-                    "cond_uncond_batched": True, "finite": ok,
-                    "mfma_frac_algorithmic": (S * world / ds) * FWD_FLOP_PER_IMG * 2 * a.sample_steps / (PEAK_BF16 * world)}
+        sampling = {"metric": "500-step CFG sample img/s", "value": n_images / ds, "unit": "img/s",
+                    "workload": "configs[3]: 500-step cosine DDPM, eta 1.0, CFG 6.0 (cond+uncond batched), "
+                                "11 labels x 64 samples = 704 images, batch-sharded over the ranks"
+                                if a.sample_images < 0 else "%d images per GPU (reduced: NOT configs[3])" % a.sample_images,
+                    "images": n_images, "images_per_launch": chunk, "steps": a.sample_steps, "seconds": ds,
+                    "guidance": 6.0, "eta": 1.0, "cond_uncond_batched": True, "finite": ok,
+                    "mfma_frac_algorithmic": (n_images / ds) * FWD_FLOP_PER_IMG * 2 * a.sample_steps / (PEAK_BF16 * world)}
         # DPM-Solver++(2M) leg (reference main_stl10.py:634-703, its default 50 steps): the same
         # images on the fused multistep kernel.  Secondary: fewer UNet evaluations per image, not a faster kernel.
         from diffusion_model_amd.dpm_solver import DPMSolverMultistepScheduler
@@ -470,26 +603,28 @@ def main():
                                           beta_schedule="scaled_linear", prediction_type="v_prediction",
                                           algorithm_type="dpmsolver++", solver_order=2)
         gd = torch.where(labels == 10, 0.0, 6.0)
-        smp.sample_dpm(z[:S], labels, dpm, cfg_scale=gd, num_inference_steps=3)
+        if S:
+            smp.sample_dpm(z[:wl], labels[:wl], dpm, cfg_scale=gd[:wl], num_inference_steps=3)
         barrier()
         t1 = time.perf_counter()
-        xd = smp.sample_dpm(z, labels, dpm, cfg_scale=gd, num_inference_steps=50)
+        xd = torch.cat([smp.sample_dpm(z[c:c + chunk], labels[c:c + chunk], dpm, cfg_scale=gd[c:c + chunk],
+                                       num_inference_steps=50) for c in range(0, S, chunk)]) if S else z
         barrier()
         dd = time.perf_counter() - t1
         if world > 1:
             tt = torch.tensor([dd], device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dd = float(tt.item())
-        sampling["dpm_solver_pp_2m"] = {"value": S * world / dd, "unit": "img/s", "steps": 50, "seconds": dd,
+        sampling["dpm_solver_pp_2m"] = {"value": n_images / dd, "unit": "img/s", "steps": 50, "seconds": dd,
                                         "guidance": 6.0, "finite": bool(torch.isfinite(xd).all().item())}
-        if elided is not None:  # the same sampling run with the dead attention work skipped (secondary, see above)
+        if elided is not None and S:  # one launch of the same sampling run with the dead attention work skipped (secondary)
             from diffusion_model_amd import unet as U
             U.ELIDE_DEAD_ATTENTION[0] = True
             try:
-                smp.sample(z[:S], labels, 6.0, 1.0, num_time_steps=500, t_stop=497)
+                smp.sample(z[:wl], labels[:wl], 6.0, 1.0, num_time_steps=500, t_stop=497)
                 barrier()
                 t1 = time.perf_counter()
-                x0e = smp.sample(z, labels, 6.0, 1.0, num_time_steps=a.sample_steps)
+                x0e = smp.sample(z[:wl], labels[:wl], 6.0, 1.0, num_time_steps=a.sample_steps)
                 barrier()
                 dse = time.perf_counter() - t1
             finally:
@@ -498,7 +633,8 @@ def main():
                 tt = torch.tensor([dse], device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dse = float(tt.item())
-            elided["sampling_value"] = S * world / dse
+            elided["sampling_value"] = wl * world / dse
+            elided["sampling_images"] = wl * world
             elided["sampling_finite"] = bool(torch.isfinite(x0e).all().item())
 
     if rank != 0:
@@ -538,12 +674,16 @@ def main():
             sec = sum(e0.elapsed_time(e1) for e0, e1 in probe["pairs"]) * 1e-3 / len(probe["pairs"])
         # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # collected in separate rocprofv3 --pmc runs of the same kernel and shape; bench.py cannot run PMC itself)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_dominant_conv.json")
-        if a.batch == 64 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_bytes"]
+        traffic = traffic_src = None
+        for name in ("r03_pmc_dominant_conv.json", "r02_pmc_dominant_conv.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if a.batch == 64 and os.path.exists(pmc):
+                traffic, traffic_src = json.load(open(pmc))["traffic_bytes"], "profiles/" + name
+                break
         out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                            "frac": fl / sec / PEAK_BF16, "traffic": traffic,
+                           "traffic_source": (traffic_src or "none") + " (separate rocprofv3 --pmc passes of this kernel and "
+                                             "shape, FETCH_SIZE x2-corrected + WRITE_SIZE; not re-measured by this run)",
                            "kernel": "%s: nearest-x2 + conv3x3 128->128 48->96 (L4.upsample.conv), B=%d" % (variant, a.batch),
                            "avg_launch_us": sec * 1e6, "flop_per_launch": fl,
                            "launches_timed": len(probe["pairs"]) if probe else 0,
@@ -560,6 +700,8 @@ def main():
             others.append({"kernel": f"{var_o}: {what}", "avg_launch_us": sec_o * 1e6,
                            "achieved": fl_o / sec_o / 1e12, "frac": fl_o / sec_o / PEAK_BF16})
         out["roofline"]["other_conv_kernels_back_to_back"] = others
+        out["roofline_hbm"] = hbm_rooflines(dev, a.batch)
+        out["roofline_attention"] = attention_roofline(dev, a.batch, a.dropout)
     if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)          # flushed before the process group is torn down
