@@ -122,6 +122,30 @@ _SIGS = {
     "dm_grad_norm_clipcoef": (c_int, [c_void_p, c_long, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_adamw_ema_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float,
                                   c_float, c_float, c_float, c_float, c_int, C.c_double, c_float, c_int, c_void_p]),
+    # ---- fp32 compute mode (include/dm_hip.h, last section)
+    "dm_packed_weight_f32_bytes": (c_long, [c_int, c_int, c_int]),
+    "dm_pack_weight_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dm_conv3x3_f32": (c_int, [C.POINTER(ConvArgs), c_void_p]),
+    "dm_gemm_f32": (c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "dm_pool2_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "dm_wgrad_f32_workspace_bytes": (c_long, [c_int] * 7),
+    "dm_wgrad_f32": (c_int, [C.POINTER(WgradArgs), c_void_p]),
+    "dm_gn_silu_fwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_long, c_void_p]),
+    "dm_gn_f32_workspace_bytes": (c_long, [c_int, c_int]),
+    "dm_gn_silu_bwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p, c_long, c_void_p]),
+    "dm_attn_fwd_f32": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "dm_attn_bwd_f32": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "dm_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_int, c_void_p]),
+    "dm_add_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "dm_silu_bwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "dm_colsum_f32": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dm_film_fwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_float, c_ulonglong,
+                                c_void_p]),
+    "dm_film_bwd_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int,
+                                c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -7,7 +7,7 @@
 static thread_local int g_last_hip_error = 0;
 static thread_local const char* g_last_variant = "";
 extern "C" void dm_note_hip_error(int code) { g_last_hip_error = code; }
-extern "C" int dm_abi_version(void) { return 3; }   // 2: dm_conv_args / dm_wgrad_args grew norm_scale, norm_shift; 3: dm_attn_args grew workspace, ws_bytes
+extern "C" int dm_abi_version(void) { return 4; }   // 4: fp32 compute mode entry points (dm_f32.hip); 2: dm_conv_args / dm_wgrad_args grew norm_scale, norm_shift; 3: dm_attn_args grew workspace, ws_bytes
 extern "C" const char* dm_target_arch(void) { return "gfx950"; }
 extern "C" const char* dm_last_hip_error(void) {
   return g_last_hip_error ? hipGetErrorString((hipError_t)g_last_hip_error) : "";

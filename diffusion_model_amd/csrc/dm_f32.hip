@@ -1,0 +1,994 @@
+// fp32 COMPUTE MODE for gfx950: the same operators as the bf16 path on fp32 NHWC activations with fp32 weights.
+//
+// The reference is fp32 end to end (unet.py:74-75,113-139; main_stl10.py:474-482) and the north star asks for parity
+// "within 1e-4 in fp32".  This file is that mode: every contraction runs on v_mfma_f32_16x16x4_f32 (fp32 inputs, an
+// exact fp32 FMA chain at the fp32 vector rate, 157 TFLOP/s -- MI355X_MICROARCH.md, matrix cores), attention on fp32
+// VALU flash-style kernels (no N x N matrix in memory), GroupNorm / elementwise work in fp32 throughout.  It is the
+// parity / reference-precision mode, built for exactness and generality (any channel count, any head dim <= 128, any
+// context length), not tuned like the bf16 kernels that carry the headline: one implicit-GEMM kernel serves 3x3 s1 / s2 /
+// nearest-x2 / zero-insert convolutions, 1x1 convolutions and linears; one kernel family serves every attention shape.
+//
+// Fragment layout of v_mfma_f32_16x16x4_f32 (A 16x4, B 4x16, D 16x16; lane l): a = A[l % 16][l / 16],
+// b = B[l / 16][l % 16], d[j] = D[4 * (l / 16) + j][l % 16].  As in the bf16 kernels the weights are the A operand
+// (rows = output channels) and pixels the B operand, so a lane ends up with 4 consecutive output channels of one pixel
+// (16-byte NHWC stores, per-channel bias / time-embedding adds stay in-lane).
+#include "dm_common.h"
+
+namespace {
+
+constexpr int TP = 64;      // pixels per workgroup tile
+constexpr int TC = 64;      // output channels per workgroup tile
+constexpr int KC = 32;      // k (input channels) per LDS stage
+constexpr int XLD = KC + 4; // Xs[pixel][k] row stride (floats): 16-byte aligned rows
+constexpr int WLD = TC + 16; // Ws[k][cout] row stride: lanes 16..31 of a fragment read land 16 banks away (conflict-free)
+
+struct ConvF {
+  const float* x; long ldx;
+  const float* w; int Kp, Np;          // packed fp32 weights [taps][Kp][Np]
+  const float* bias; const float* chan_add; const float* res; long ldr;
+  float* y; long ldy;
+  int B, Hi, Wi, Cin, Cout, Ho, Wo, mode, taps;
+  long M; int rows_per_batch; int n_valid; int act_silu_in;
+  uint32_t drop_seed, drop_thresh; float drop_scale; const uint32_t* seed_ctr;
+};
+
+// source pixel (linear index into x's [B*Hi*Wi] rows) of output pixel m under tap (kh, kw); -1 = zero padding
+__device__ __forceinline__ long conv_src(const ConvF& p, long m, int kh, int kw) {
+  if (m >= p.M) return -1;
+  if (p.taps == 1) return m;
+  const int wo = (int)(m % p.Wo);
+  const long t = m / p.Wo;
+  const int ho = (int)(t % p.Ho);
+  const int b = (int)(t / p.Ho);
+  int vh, vw;
+  if (p.mode == 1) { vh = 2 * ho + kh - 1; vw = 2 * wo + kw - 1; } else { vh = ho + kh - 1; vw = wo + kw - 1; }
+  if (p.mode == 2 || p.mode == 3) {
+    if (vh < 0 || vw < 0 || vh >= 2 * p.Hi || vw >= 2 * p.Wi) return -1;
+    if (p.mode == 3 && ((vh | vw) & 1)) return -1;     // zero-inserted positions
+    vh >>= 1; vw >>= 1;
+  } else if (vh < 0 || vw < 0 || vh >= p.Hi || vw >= p.Wi) {
+    return -1;
+  }
+  return ((long)b * p.Hi + vh) * p.Wi + vw;
+}
+
+// grid (ceil(M / 64), Np / 64), 256 threads
+__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvF p) {
+  __shared__ __attribute__((aligned(16))) float Xs[TP * XLD];
+  __shared__ __attribute__((aligned(16))) float Ws[KC * WLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long m0 = (long)blockIdx.x * TP;
+  const int n0 = blockIdx.y * TC;
+  // staging roles: X: pixel tid >> 2, float4 slots (tid & 3) and (tid & 3) + 4 of the 8 per row; W: k row tid >> 3,
+  // float4 slots (tid & 7) and (tid & 7) + 8 of the 16 per row
+  const int xp = tid >> 2, xf = tid & 3;
+  const int wk = tid >> 3, wf = tid & 7;
+  const int ncc = (p.Cin + KC - 1) / KC;
+  const int nstage = p.taps * ncc;
+  const bool vec = (p.ldx % 4 == 0) && ((reinterpret_cast<unsigned long long>(p.x) & 15) == 0);
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xr[2], wr[2];
+  auto fetch = [&](int s) {
+    const int tap = s / ncc, cc = s - tap * ncc;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const long src = conv_src(p, m0 + xp, kh, kw);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ci = cc * KC + (xf + 4 * h) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (src >= 0) {
+        const float* q = p.x + src * p.ldx + ci;
+        if (vec && ci + 3 < p.Cin) v = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (ci + j < p.Cin) v[j] = q[j];
+        }
+        if (p.act_silu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = dm_silu(v[j]);
+        }
+      }
+      xr[h] = v;
+      // weights: row k = cc*KC + wk of tap, columns n0 + (wf + 8h)*4 (always inside the zero-padded pack)
+      const long wo = ((long)tap * p.Kp + cc * KC + wk) * p.Np + n0 + (wf + 8 * h) * 4;
+      wr[h] = (cc * KC + wk < p.Kp) ? *reinterpret_cast<const f32x4*>(p.w + wo) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(0);
+  for (int s = 0; s < nstage; ++s) {
+    __syncthreads();   // the previous stage's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&Xs[xp * XLD + (xf + 4 * h) * 4]) = xr[h];
+      *reinterpret_cast<f32x4*>(&Ws[wk * WLD + (wf + 8 * h) * 4]) = wr[h];
+    }
+    __syncthreads();
+    if (s + 1 < nstage) fetch(s + 1);   // in flight while this stage's MFMAs run
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int k = ks * 4 + (lane >> 4);
+      const float bfrag = Xs[(wave * 16 + (lane & 15)) * XLD + k];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float afrag = Ws[k * WLD + mt * 16 + (lane & 15)];
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: lane holds couts n0 + 16 mt + 4 (lane >> 4) + j of pixel m0 + 16 wave + (lane & 15)
+  const long pix = m0 + wave * 16 + (lane & 15);
+  if (pix >= p.M) return;
+  const long bb = p.taps == 1 ? pix / p.rows_per_batch : pix / ((long)p.Ho * p.Wo);
+  uint32_t rs = 0u;
+  if (p.drop_thresh) rs = dm_drop_row(dm_eff_seed(p.drop_seed, p.seed_ctr), (uint32_t)pix);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int co = n0 + mt * 16 + 4 * (lane >> 4);
+    if (co >= p.n_valid) continue;
+    f32x4 v = acc[mt];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (co + j >= p.n_valid) continue;
+      float f = v[j];
+      if (p.bias) f += p.bias[co + j];
+      if (p.chan_add) f += p.chan_add[bb * p.Cout + co + j];
+      if (p.drop_thresh) {
+        const uint32_t bits = dm_drop_bits(rs, ((uint32_t)(co + j)) >> 1);
+        f = dm_keep16(bits, (uint32_t)(co + j), p.drop_thresh) ? f * p.drop_scale : 0.f;
+      }
+      if (p.res) f += p.res[pix * p.ldr + co + j];
+      v[j] = f;
+    }
+    float* o = p.y + pix * p.ldy + co;
+    if (co + 3 < p.n_valid && (p.ldy % 4 == 0) && ((reinterpret_cast<unsigned long long>(p.y) & 15) == 0))
+      *reinterpret_cast<f32x4*>(o) = v;
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (co + j < p.n_valid) o[j] = v[j];
+    }
+  }
+}
+
+// dst[tap][k][n] (Kp x Np, zero padded) from the reference layout.  transpose = 0: W[n][k][kh][kw];
+// transpose = 1 (data-gradient operand): W is [k][n][kh][kw] and the taps are flipped.
+__global__ void pack_f32_kernel(const float* __restrict__ w, float* __restrict__ dst, int N, int K, int taps,
+                                int transpose, int Kp, int Np) {
+  const long total = (long)taps * Kp * Np;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Np);
+    const long r = i / Np;
+    const int k = (int)(r % Kp);
+    const int tap = (int)(r / Kp);
+    float v = 0.f;
+    if (n < N && k < K) {
+      if (!transpose) v = w[((long)n * K + k) * taps + tap];
+      else v = (taps == 9) ? w[((long)k * N + n) * 9 + (8 - tap)] : w[(long)k * N + n];
+    }
+    dst[i] = v;
+  }
+}
+
+// out[b][ho/2][wo/2][c] = sum of the 2x2 block (data-gradient of the nearest-x2 upsample)
+__global__ void pool2_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long ldy, int B, int Ho, int Wo, int C) {
+  const int H2 = Ho >> 1, W2 = Wo >> 1;
+  const long total = (long)B * H2 * W2 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2);
+    const int b = (int)(r / H2);
+    const float* s = x + (((long)b * Ho + 2 * h2) * Wo + 2 * w2) * C + c;
+    y[(((long)b * H2 + h2) * W2 + w2) * ldy + c] = (s[0] + s[C]) + (s[(long)Wo * C] + s[(long)Wo * C + C]);
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient
+struct WgradF {
+  const float* x; long ldx; const float* dy; long lddy;
+  float* slab;                          // [nsplit][taps][Cop][Cip] partials
+  int B, Hi, Wi, Cin, Cout, Ho, Wo, mode, taps, act_silu_in;
+  long M; int nsplit; long per_split; int Cip, Cop;
+};
+
+// grid (Cip / 64, Cop / 64, taps * nsplit): D[co][ci] = sum over the split's output pixels of dy[pix][co] * x[src(pix, tap)][ci]
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradF p) {
+  __shared__ __attribute__((aligned(16))) float Ds[KC * WLD];   // dy tile  [pixel][co]
+  __shared__ __attribute__((aligned(16))) float Xs[KC * WLD];   // x tile   [pixel][ci]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int tap = blockIdx.z % p.taps, split = blockIdx.z / p.taps;
+  const int kh = tap / 3, kw = tap - 3 * kh;
+  const long mb = (long)split * p.per_split, me = mb + p.per_split < p.M ? mb + p.per_split : p.M;
+  const int pp = tid >> 3, pf = tid & 7;   // pixel of the 32-pixel stage, float4 slots pf and pf + 8 of the 16 per row
+  ConvF g{};   // geometry only (conv_src)
+  g.Hi = p.Hi; g.Wi = p.Wi; g.Ho = p.Ho; g.Wo = p.Wo; g.mode = p.mode; g.taps = p.taps; g.M = me;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dr[2], xr[2];
+  const bool vecx = (p.ldx % 4 == 0) && ((reinterpret_cast<unsigned long long>(p.x) & 15) == 0);
+  const bool vecd = (p.lddy % 4 == 0) && ((reinterpret_cast<unsigned long long>(p.dy) & 15) == 0);
+  auto fetch = [&](long m) {
+    const long pix = m + pp;
+    const long src = conv_src(g, pix, kh, kw);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = (pf + 8 * h) * 4;
+      f32x4 d = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < me) {
+        const float* q = p.dy + pix * p.lddy + co0 + c;
+        if (vecd && co0 + c + 3 < p.Cout) d = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (co0 + c + j < p.Cout) d[j] = q[j];
+        }
+      }
+      if (src >= 0) {
+        const float* q = p.x + src * p.ldx + ci0 + c;
+        if (vecx && ci0 + c + 3 < p.Cin) v = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (ci0 + c + j < p.Cin) v[j] = q[j];
+        }
+        if (p.act_silu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = dm_silu(v[j]);
+        }
+      }
+      dr[h] = d; xr[h] = v;
+    }
+  };
+  if (mb < me) fetch(mb);
+  for (long m = mb; m < me; m += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f32x4*>(&Ds[pp * WLD + (pf + 8 * h) * 4]) = dr[h];
+      *reinterpret_cast<f32x4*>(&Xs[pp * WLD + (pf + 8 * h) * 4]) = xr[h];
+    }
+    __syncthreads();
+    if (m + KC < me) fetch(m + KC);
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int k = ks * 4 + (lane >> 4);
+      const float afrag = Ds[k * WLD + wave * 16 + (lane & 15)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float bfrag = Xs[k * WLD + nt * 16 + (lane & 15)];
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag, bfrag, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  // slab[split][tap][co][ci]: lane holds co = co0 + 16 wave + 4 (lane >> 4) + j, ci = ci0 + 16 nt + (lane & 15)
+  float* s = p.slab + (((long)split * p.taps + tap) * p.Cop) * p.Cip;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      s[(long)(co0 + wave * 16 + 4 * (lane >> 4) + j) * p.Cip + ci0 + nt * 16 + (lane & 15)] = acc[nt][j];
+}
+
+// dw[co][ci][tap] += sum over splits (fixed order) -- bit-reproducible
+__global__ void wgrad_f32_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int taps,
+                                        int Cop, int Cip, int n_valid, int k_valid) {
+  const long total = (long)n_valid * k_valid * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % k_valid);      // slab order (ci fastest): coalesced reads of the nsplit partials
+    const long r = i / k_valid;
+    const int co = (int)(r % n_valid), tap = (int)(r / n_valid);
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += slab[(((long)s * taps + tap) * Cop + co) * Cip + ci];
+    dw[((long)co * k_valid + ci) * taps + tap] += a;
+  }
+}
+
+// column sums in two ordered stages: part[chunk][c] = sum of the chunk's rows; out[c] (+)= sum over chunks
+__global__ __launch_bounds__(256) void colsum_part_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ part,
+                                                               long rows, int C, int nchunk) {
+  const int chunk = blockIdx.x;
+  const long per = (rows + nchunk - 1) / nchunk;
+  const long r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (long r = r0; r < r1; ++r) a += x[r * ldx + c];
+    part[(long)chunk * C + c] = a;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_batch_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
+                                                                int rows, int C, int accumulate) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += x[((long)b * rows + r) * ldx + c];
+    if (accumulate) out[(long)b * C + c] += a; else out[(long)b * C + c] = a;
+  }
+}
+__global__ void colsum_final_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk, int n_valid,
+                                        int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_valid) return;
+  float a = 0.f;
+  for (int k = 0; k < nchunk; ++k) a += part[(long)k * C + c];
+  if (accumulate) out[c] += a; else out[c] = a;
+}
+
+// ------------------------------------------------------------------ GroupNorm + SiLU
+// One workgroup per (sample, group): statistics in DOUBLE (sum, sum of squares over <= 10^5 elements), then the apply
+// pass from the same workgroup (the slab is L2-resident).  stats[b][g] = {mean, rstd}.
+__global__ __launch_bounds__(256) void gn_fwd_f32_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ chan_add,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, long ldy, float* __restrict__ stats, int HW,
+                                                         int C, int G, float eps, int act) {
+  __shared__ double red[2][256];
+  __shared__ float s_ms[2];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
+  const int cpg = C / G;
+  const long n = (long)HW * cpg;
+  const float* xb = x + (long)b * HW * ldx + g * cpg;
+  const float* ab = chan_add ? chan_add + (long)b * C + g * cpg : nullptr;
+  double s = 0.0, ss = 0.0;
+  for (long i = tid; i < n; i += 256) {
+    const int c = (int)(i % cpg);
+    const long pix = i / cpg;
+    const float f = xb[pix * ldx + c] + (ab ? ab[c] : 0.f);
+    s += f; ss += (double)f * f;
+  }
+  red[0][tid] = s; red[1][tid] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mean = red[0][0] / (double)n;
+    double var = red[1][0] / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    s_ms[0] = (float)mean; s_ms[1] = rstd;
+    stats[((long)b * G + g) * 2] = (float)mean; stats[((long)b * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  const float mean = s_ms[0], rstd = s_ms[1];
+  float* yb = y + (long)b * HW * ldy + g * cpg;
+  for (long i = tid; i < n; i += 256) {
+    const int c = (int)(i % cpg);
+    const long pix = i / cpg;
+    const float f = xb[pix * ldx + c] + (ab ? ab[c] : 0.f);
+    const float z = (f - mean) * rstd * gamma[g * cpg + c] + beta[g * cpg + c];
+    yb[pix * ldy + c] = act ? z / (1.f + expf(-z)) : z;
+  }
+}
+
+// backward, one workgroup per (sample, group): pass 1 sums dz and dz*xhat per channel of the group (double), pass 2
+// writes dx = rstd (dz gamma - m1 - xhat m2) [dropout mask] [+ add_in]; per-(sample, channel) partials of dgamma /
+// dbeta / column sums of dx go to part[b][c][3] and are summed over b, in order, by gn_bwd_params_f32_kernel.
+__global__ __launch_bounds__(256) void gn_bwd_f32_kernel(
+    const float* __restrict__ x, long ldx, const float* __restrict__ chan_add, const float* __restrict__ dy, long lddy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
+    const float* __restrict__ add_in, long ldadd, float* __restrict__ dx, long lddx, float* __restrict__ part, int HW, int C,
+    int G, int act, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum,
+    const uint32_t* __restrict__ seed_ctr) {
+  constexpr int MAXCPG = 128;
+  __shared__ double r1[256], r2[256];
+  __shared__ double c1[MAXCPG], c2[MAXCPG];
+  __shared__ float s_m[2];
+  const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int rows = 256 / cpg;               // pixel rows handled in parallel (cpg divides 256)
+  const int c = tid % cpg, prow = tid / cpg;
+  const int ch = g * cpg + c;
+  const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+  const float ga = gamma[ch], be = beta[ch], add = chan_add ? chan_add[(long)b * C + ch] : 0.f;
+  if (drop_thresh) drop_seed = dm_eff_seed(drop_seed, seed_ctr);
+  const bool active = prow < rows;
+  double s1 = 0.0, s2 = 0.0;
+  auto dzxh = [&](long gp, float& dz, float& xh) {
+    xh = (x[gp * ldx + ch] + add - mean) * rstd;
+    dz = dy[gp * lddy + ch];
+    if (act) {
+      const float z = xh * ga + be;
+      const float sg = 1.f / (1.f + expf(-z));
+      dz *= sg * (1.f + z * (1.f - sg));
+    }
+  };
+  if (active)
+    for (int pix = prow; pix < HW; pix += rows) {
+      float dz, xh;
+      dzxh((long)b * HW + pix, dz, xh);
+      s1 += dz; s2 += (double)dz * xh;
+    }
+  r1[tid] = active ? s1 : 0.0; r2[tid] = active ? s2 : 0.0;
+  __syncthreads();
+  if (tid < cpg) {   // channel sums over the pixel rows (fixed order)
+    double a1 = 0.0, a2 = 0.0;
+    for (int pr = 0; pr < rows; ++pr) { a1 += r1[pr * cpg + tid]; a2 += r2[pr * cpg + tid]; }
+    c1[tid] = a1; c2[tid] = a2;
+    part[((long)b * C + g * cpg + tid) * 3 + 0] = (float)a2;   // dgamma share
+    part[((long)b * C + g * cpg + tid) * 3 + 1] = (float)a1;   // dbeta share
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < cpg; ++k) { m1 += (double)gamma[g * cpg + k] * c1[k]; m2 += (double)gamma[g * cpg + k] * c2[k]; }
+    const double inv = 1.0 / ((double)cpg * (double)HW);
+    s_m[0] = (float)(m1 * inv); s_m[1] = (float)(m2 * inv);
+  }
+  __syncthreads();
+  const float m1 = s_m[0], m2 = s_m[1];
+  double cs = 0.0;
+  if (active)
+    for (int pix = prow; pix < HW; pix += rows) {
+      const long gp = (long)b * HW + pix;
+      float dz, xh;
+      dzxh(gp, dz, xh);
+      float r = rstd * (dz * ga - m1 - xh * m2);
+      if (drop_thresh) {
+        const uint32_t rs = dm_drop_row(drop_seed, (uint32_t)gp);
+        r = dm_keep16(dm_drop_bits(rs, ((uint32_t)ch) >> 1), (uint32_t)ch, drop_thresh) ? r * drop_scale : 0.f;
+      }
+      if (add_in) r += add_in[gp * ldadd + ch];
+      dx[gp * lddx + ch] = r;
+      cs += r;
+    }
+  if (dx_colsum) {
+    __syncthreads();
+    r1[tid] = active ? cs : 0.0;
+    __syncthreads();
+    if (tid < cpg) {
+      double a = 0.0;
+      for (int pr = 0; pr < rows; ++pr) a += r1[pr * cpg + tid];
+      dx_colsum[(long)b * C + g * cpg + tid] += (float)a;   // this (sample, channel) belongs to this workgroup alone
+    }
+  }
+}
+__global__ void gn_bwd_params_f32_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, d = 0.f;
+  for (int b = 0; b < B; ++b) { a += part[((long)b * C + c) * 3]; d += part[((long)b * C + c) * 3 + 1]; }
+  dgamma[c] += a; dbeta[c] += d;
+}
+
+// ------------------------------------------------------------------ attention (fp32 VALU, flash style)
+// thread = (row, part): a head's HD dims are split over P adjacent lanes (HD / P <= 32 floats per thread), partial dot
+// products are summed with xor-shuffles.  Keys / values (queries / dO in the key-major backward) are staged 64 rows at
+// a time in LDS and read by broadcast.
+struct AttnF {
+  const float* q; long ldq; const float* k; long ldk; const float* v; long ldv;
+  float* o; long ldo; float* lse;
+  const float* d_o; long lddo; float* dq; long lddq; float* dk; long lddk; float* dv; long lddv; float* delta;
+  int B, H, Nq, Nk; float scale;
+  uint32_t drop_seed, drop_thresh; float drop_scale; const uint32_t* seed_ctr;
+};
+constexpr int at_rows(int hd) { return hd > 64 ? 32 : 64; }   // staged rows per block (static LDS <= 64 KiB)
+
+__device__ __forceinline__ bool attn_keep_f32(uint32_t rs, int col, uint32_t thresh) {
+  return dm_keep16(dm_drop_bits(rs, ((uint32_t)col) >> 1), (uint32_t)col, thresh);
+}
+
+template <int HD, int P>
+__device__ __forceinline__ float part_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < P; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// grid (ceil(Nq / (256 / P)), H, B)
+template <int HD, int P>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const AttnF p) {
+  constexpr int D = HD / P, RPB = 256 / P, AT = at_rows(HD);
+  __shared__ __attribute__((aligned(16))) float Ks[AT * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[AT * HD];
+  const int tid = threadIdx.x, part = tid % P, row = blockIdx.x * RPB + tid / P;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool live = row < p.Nq;
+  float q[D], o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    q[d] = live ? p.q[((long)b * p.Nq + row) * p.ldq + h * HD + part * D + d] * p.scale : 0.f;
+    o[d] = 0.f;
+  }
+  float m = -1e30f, l = 0.f;   // (finite: the build uses -ffast-math)
+  uint32_t rs = 0u;
+  if (p.drop_thresh) rs = dm_drop_row(dm_eff_seed(p.drop_seed, p.seed_ctr), (uint32_t)(((long)b * p.H + h) * p.Nq + row));
+  for (int k0 = 0; k0 < p.Nk; k0 += AT) {
+    const int nk = p.Nk - k0 < AT ? p.Nk - k0 : AT;
+    __syncthreads();
+    for (int i = tid; i < nk * HD; i += 256) {
+      const int kk = i / HD, d = i - kk * HD;
+      Ks[i] = p.k[((long)b * p.Nk + k0 + kk) * p.ldk + h * HD + d];
+      Vs[i] = p.v[((long)b * p.Nk + k0 + kk) * p.ldv + h * HD + d];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < nk; ++kk) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += q[d] * Ks[kk * HD + part * D + d];
+      s = part_sum<HD, P>(s);
+      const float mn = fmaxf(m, s);
+      const float corr = expf(m - mn), pr = expf(s - mn);
+      l = l * corr + pr;
+      float pd = pr;
+      if (p.drop_thresh) pd = attn_keep_f32(rs, k0 + kk, p.drop_thresh) ? pr * p.drop_scale : 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] = o[d] * corr + pd * Vs[kk * HD + part * D + d];
+      m = mn;
+    }
+  }
+  if (!live) return;
+  const float inv = 1.f / l;
+  if (p.o) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) p.o[((long)b * p.Nq + row) * p.ldo + h * HD + part * D + d] = o[d] * inv;
+  }
+  if (p.lse && part == 0) p.lse[((long)b * p.H + h) * p.Nq + row] = m + logf(l);
+}
+
+// dq (thread = (query, part)); also writes delta[b][h][q] = rowsum(dO * O)
+template <int HD, int P>
+__global__ __launch_bounds__(256) void attn_bwd_q_f32_kernel(const AttnF p) {
+  constexpr int D = HD / P, RPB = 256 / P, AT = at_rows(HD);
+  __shared__ __attribute__((aligned(16))) float Ks[AT * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[AT * HD];
+  const int tid = threadIdx.x, part = tid % P, row = blockIdx.x * RPB + tid / P;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool live = row < p.Nq;
+  float q[D], d_o[D], dq[D];
+  float dl = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const long c = h * HD + part * D + d;
+    q[d] = live ? p.q[((long)b * p.Nq + row) * p.ldq + c] * p.scale : 0.f;
+    d_o[d] = live ? p.d_o[((long)b * p.Nq + row) * p.lddo + c] : 0.f;
+    dl += live ? d_o[d] * p.o[((long)b * p.Nq + row) * p.ldo + c] : 0.f;
+    dq[d] = 0.f;
+  }
+  dl = part_sum<HD, P>(dl);
+  const float lse = live ? p.lse[((long)b * p.H + h) * p.Nq + row] : 0.f;
+  if (live && part == 0) p.delta[((long)b * p.H + h) * p.Nq + row] = dl;
+  uint32_t rs = 0u;
+  if (p.drop_thresh) rs = dm_drop_row(dm_eff_seed(p.drop_seed, p.seed_ctr), (uint32_t)(((long)b * p.H + h) * p.Nq + row));
+  for (int k0 = 0; k0 < p.Nk; k0 += AT) {
+    const int nk = p.Nk - k0 < AT ? p.Nk - k0 : AT;
+    __syncthreads();
+    for (int i = tid; i < nk * HD; i += 256) {
+      const int kk = i / HD, d = i - kk * HD;
+      Ks[i] = p.k[((long)b * p.Nk + k0 + kk) * p.ldk + h * HD + d];
+      Vs[i] = p.v[((long)b * p.Nk + k0 + kk) * p.ldv + h * HD + d];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < nk; ++kk) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += q[d] * Ks[kk * HD + part * D + d];
+        dp += d_o[d] * Vs[kk * HD + part * D + d];
+      }
+      s = part_sum<HD, P>(s);
+      dp = part_sum<HD, P>(dp);
+      const float pr = expf(s - lse);
+      if (p.drop_thresh) dp = attn_keep_f32(rs, k0 + kk, p.drop_thresh) ? dp * p.drop_scale : 0.f;
+      const float ds = pr * (dp - dl) * p.scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] += ds * Ks[kk * HD + part * D + d];
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int d = 0; d < D; ++d) p.dq[((long)b * p.Nq + row) * p.lddq + h * HD + part * D + d] = dq[d];
+}
+
+// dk, dv (thread = (key, part)); queries / dO / lse / delta staged 64 at a time
+template <int HD, int P>
+__global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const AttnF p) {
+  constexpr int D = HD / P, RPB = 256 / P, AT = at_rows(HD);
+  __shared__ __attribute__((aligned(16))) float Qs[AT * HD];
+  __shared__ __attribute__((aligned(16))) float Os[AT * HD];
+  __shared__ float Ls[AT], Dl[AT];
+  const int tid = threadIdx.x, part = tid % P, row = blockIdx.x * RPB + tid / P;   // row = key index
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool live = row < p.Nk;
+  float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const long c = h * HD + part * D + d;
+    k[d] = live ? p.k[((long)b * p.Nk + row) * p.ldk + c] : 0.f;
+    v[d] = live ? p.v[((long)b * p.Nk + row) * p.ldv + c] : 0.f;
+    dk[d] = 0.f; dv[d] = 0.f;
+  }
+  const uint32_t seed = p.drop_thresh ? dm_eff_seed(p.drop_seed, p.seed_ctr) : 0u;
+  for (int q0 = 0; q0 < p.Nq; q0 += AT) {
+    const int nq = p.Nq - q0 < AT ? p.Nq - q0 : AT;
+    __syncthreads();
+    for (int i = tid; i < nq * HD; i += 256) {
+      const int qq = i / HD, d = i - qq * HD;
+      Qs[i] = p.q[((long)b * p.Nq + q0 + qq) * p.ldq + h * HD + d] * p.scale;
+      Os[i] = p.d_o[((long)b * p.Nq + q0 + qq) * p.lddo + h * HD + d];
+    }
+    if (tid < nq) {
+      Ls[tid] = p.lse[((long)b * p.H + h) * p.Nq + q0 + tid];
+      Dl[tid] = p.delta[((long)b * p.H + h) * p.Nq + q0 + tid];
+    }
+    __syncthreads();
+    for (int qq = 0; qq < nq; ++qq) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += Qs[qq * HD + part * D + d] * k[d];
+        dp += Os[qq * HD + part * D + d] * v[d];
+      }
+      s = part_sum<HD, P>(s);
+      dp = part_sum<HD, P>(dp);
+      const float pr = expf(s - Ls[qq]);
+      float pz = pr;
+      if (p.drop_thresh) {
+        const uint32_t rs = dm_drop_row(seed, (uint32_t)(((long)b * p.H + h) * p.Nq + q0 + qq));
+        const bool keep = attn_keep_f32(rs, row, p.drop_thresh);
+        pz = keep ? pr * p.drop_scale : 0.f;
+        dp = keep ? dp * p.drop_scale : 0.f;
+      }
+      const float ds = pr * (dp - Dl[qq]);   // Qs already carries `scale`
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        dv[d] += pz * Os[qq * HD + part * D + d];
+        dk[d] += ds * Qs[qq * HD + part * D + d];
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    p.dk[((long)b * p.Nk + row) * p.lddk + h * HD + part * D + d] = dk[d];
+    p.dv[((long)b * p.Nk + row) * p.lddv + h * HD + part * D + d] = dv[d];
+  }
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW, long ldy,
+                                        int Cpad) {
+  const long total = (long)B * HW * Cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long bp = i / Cpad;
+    const int pix = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    y[bp * ldy + c] = c < C ? x[((long)b * C + c) * HW + pix] : 0.f;
+  }
+}
+__global__ void add_f32_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                               float* __restrict__ o, long ldo, long P, int C) {
+  const long total = P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    o[p * ldo + c] = a[p * lda + c] + (b ? b[p * ldb + c] : 0.f);
+  }
+}
+__global__ void silu_bwd_f32_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                    float* __restrict__ dx, long lddx, long P, int C) {
+  const long total = P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const float z = x[p * ldx + c];
+    const float sg = 1.f / (1.f + expf(-z));
+    dx[p * lddx + c] = dy[p * lddy + c] * sg * (1.f + z * (1.f - sg));
+  }
+}
+__global__ void film_fwd_f32_kernel(const float* __restrict__ h, long ldh, const float* __restrict__ gb, float* __restrict__ o,
+                                    long ldo, long P, int HW, int C, uint32_t seed, uint32_t thresh, float scale,
+                                    const uint32_t* __restrict__ ctr) {
+  const long total = P * C;
+  const uint32_t seed_eff = dm_eff_seed(seed, ctr);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const float* row = gb + (p / HW) * 2 * C;
+    float f = row[c] * h[p * ldh + c] + row[C + c];
+    if (thresh) {
+      const uint32_t rs = dm_drop_row(seed_eff, (uint32_t)p);
+      f = dm_keep16(dm_drop_bits(rs, ((uint32_t)c) >> 1), (uint32_t)c, thresh) ? f * scale : 0.f;
+    }
+    o[p * ldo + c] = f;
+  }
+}
+// grid (B): dh0 = gamma * dh, dgamma[b][c] = sum over the sample's pixels of dh * h0 (one workgroup per sample: ordered)
+__global__ __launch_bounds__(256) void film_bwd_f32_kernel(const float* __restrict__ dh, long lddh, const float* __restrict__ h0,
+                                                            long ldh, const float* __restrict__ gb, float* __restrict__ dh0,
+                                                            long ldo, float* __restrict__ dgamma, int HW, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float ga = gb[(long)b * 2 * C + c];
+    double a = 0.0;
+    for (int pix = 0; pix < HW; ++pix) {
+      const long gp = (long)b * HW + pix;
+      const float d = dh[gp * lddh + c];
+      a += (double)d * h0[gp * ldh + c];
+      dh0[gp * ldo + c] = ga * d;
+    }
+    dgamma[(long)b * C + c] = (float)a;
+  }
+}
+
+inline int ew_grid_f32(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+int wgrad_f32_nsplit(long M, int Cip, int Cop, int taps) {
+  const long tiles = (long)(Cip / 64) * (Cop / 64) * taps;
+  long ns = 2048 / (tiles > 0 ? tiles : 1);
+  if (ns < 1) ns = 1;
+  const long cap = (M + 255) / 256;     // at least 256 pixels per split
+  if (ns > cap) ns = cap;
+  if (ns > 256) ns = 256;
+  return (int)ns;
+}
+constexpr int COLSUM_CHUNKS = 256;
+
+template <int HD, int P>
+int launch_attn_f32(const AttnF& p, int which, hipStream_t st) {
+  const int rpb = 256 / P;
+  if (which == 0) {
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<HD, P>), dim3((p.Nq + rpb - 1) / rpb, p.H, p.B), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_q_f32_kernel<HD, P>), dim3((p.Nq + rpb - 1) / rpb, p.H, p.B), dim3(256), 0, st, p);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_kv_f32_kernel<HD, P>), dim3((p.Nk + rpb - 1) / rpb, p.H, p.B), dim3(256), 0, st, p);
+  }
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+int dispatch_attn_f32(const AttnF& p, int hd, int which, hipStream_t st) {
+  switch (hd) {
+    case 8: return launch_attn_f32<8, 1>(p, which, st);
+    case 16: return launch_attn_f32<16, 1>(p, which, st);
+    case 32: return launch_attn_f32<32, 1>(p, which, st);
+    case 64: return launch_attn_f32<64, 2>(p, which, st);
+    case 128: return launch_attn_f32<128, 4>(p, which, st);
+    default: return DM_ERR_ARG;
+  }
+}
+
+int fill_attn(const dm_attn_args* a, AttnF& p) {
+  p.q = (const float*)a->q; p.ldq = a->ldq; p.k = (const float*)a->k; p.ldk = a->ldk; p.v = (const float*)a->v; p.ldv = a->ldv;
+  p.o = (float*)a->o; p.ldo = a->ldo; p.lse = a->lse;
+  p.d_o = (const float*)a->d_o; p.lddo = a->lddo; p.dq = (float*)a->dq; p.lddq = a->lddq; p.dk = (float*)a->dk; p.lddk = a->lddk;
+  p.dv = (float*)a->dv; p.lddv = a->lddv; p.delta = a->delta;
+  p.B = a->B; p.H = a->heads; p.Nq = a->Nq; p.Nk = a->Nk; p.scale = a->scale;
+  p.drop_seed = dm_seed32(a->drop_seed); p.drop_thresh = 0; p.drop_scale = 1.f; p.seed_ctr = dm_dropout_counter();
+  if (a->drop_p > 0.f) {
+    if (a->drop_p >= 1.f) return DM_ERR_ARG;
+    p.drop_thresh = dm_thresh16(a->drop_p);
+    p.drop_scale = dm_inv_keep(a->drop_p);
+  }
+  return DM_OK;
+}
+
+int launch_conv_f32(ConvF& p, hipStream_t st) {
+  dim3 grid((unsigned)((p.M + TP - 1) / TP), (unsigned)(p.Np / TC));
+  hipLaunchKernelGGL(conv_f32_kernel, grid, dim3(256), 0, st, p);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+}  // namespace
+
+extern "C" long dm_packed_weight_f32_bytes(int N, int K, int taps) {
+  return (long)rup(N, 64) * rup(K, 64) * taps * 4;
+}
+
+extern "C" int dm_pack_weight_f32(const float* w, float* dst, int N, int K, int taps, int transpose, dm_stream_t stream) {
+  DM_REQUIRE(w && dst && N > 0 && K > 0 && (taps == 1 || taps == 9));
+  const int Kp = rup(K, 64), Np = rup(N, 64);
+  hipLaunchKernelGGL(pack_f32_kernel, dim3(ew_grid_f32((long)taps * Kp * Np)), dim3(256), 0, (hipStream_t)stream, w, dst, N,
+                     K, taps, transpose, Kp, Np);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dm_conv3x3 on fp32 activations.  x / res / y are float*; w = dm_pack_weight_f32(taps = 9) of a weight whose padded
+// sizes equal round-up(Cin, 64) x round-up(Cout, 64); the output goes to y (or yf when y is NULL).  pool2 is not taken here
+// (DM_ERR_ARG): run the conv at full size and dm_pool2_f32 after it.
+extern "C" int dm_conv3x3_f32(const dm_conv_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->w && (a->y || a->yf) && a->B > 0 && a->Cin > 0 && a->Cout > 0);
+  DM_REQUIRE(a->mode >= 0 && a->mode <= 3 && !a->pool2 && !a->norm_scale && !a->norm_shift);
+  ConvF p{};
+  p.x = (const float*)a->x; p.ldx = a->ldx; p.w = (const float*)a->w; p.Kp = rup(a->Cin, 64); p.Np = rup(a->Cout, 64);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.res = (const float*)a->res; p.ldr = a->ldr;
+  p.y = a->y ? (float*)a->y : a->yf; p.ldy = a->y ? a->ldy : a->ldyf;
+  p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.mode = a->mode; p.taps = 9;
+  if (a->mode == 1) { DM_REQUIRE(a->H % 2 == 0 && a->W % 2 == 0); p.Ho = a->H / 2; p.Wo = a->W / 2; }
+  else if (a->mode >= 2) { p.Ho = 2 * a->H; p.Wo = 2 * a->W; }
+  else { p.Ho = a->H; p.Wo = a->W; }
+  p.M = (long)p.B * p.Ho * p.Wo; p.rows_per_batch = 1;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : a->Cout; p.act_silu_in = a->act_silu_in;
+  p.drop_seed = dm_seed32(a->drop_seed); p.drop_thresh = 0; p.drop_scale = 1.f; p.seed_ctr = dm_dropout_counter();
+  if (a->drop_p > 0.f) { DM_REQUIRE(a->drop_p < 1.f); p.drop_thresh = dm_thresh16(a->drop_p); p.drop_scale = dm_inv_keep(a->drop_p); }
+  dm_set_variant("conv_f32<64x64,mfma_f32_16x16x4>");
+  return launch_conv_f32(p, (hipStream_t)stream);
+}
+
+extern "C" int dm_gemm_f32(const dm_gemm_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->w && (a->y || a->yf) && a->M > 0 && a->K > 0 && a->N > 0);
+  ConvF p{};
+  p.x = (const float*)a->x; p.ldx = a->ldx; p.w = (const float*)a->w; p.Kp = rup(a->K, 64); p.Np = rup(a->N, 64);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.res = (const float*)a->res; p.ldr = a->ldr;
+  p.y = a->y ? (float*)a->y : a->yf; p.ldy = a->y ? a->ldy : a->ldyf;
+  p.B = 1; p.Cin = a->K; p.Cout = a->N; p.taps = 1; p.mode = 0; p.M = a->M;
+  p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1 << 30;
+  p.n_valid = a->n_valid > 0 ? a->n_valid : a->N; p.act_silu_in = a->act_silu_in;
+  p.drop_thresh = 0; p.drop_scale = 1.f;
+  dm_set_variant("gemm_f32<64x64,mfma_f32_16x16x4>");
+  return launch_conv_f32(p, (hipStream_t)stream);
+}
+
+extern "C" int dm_pool2_f32(const float* x, float* y, long ldy, int B, int Ho, int Wo, int C, dm_stream_t stream) {
+  DM_REQUIRE(x && y && B > 0 && Ho % 2 == 0 && Wo % 2 == 0 && C > 0 && ldy >= C);
+  hipLaunchKernelGGL(pool2_f32_kernel, dim3(ew_grid_f32((long)B * Ho * Wo * C / 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     ldy, B, Ho, Wo, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" long dm_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
+  long Ho = H, Wo = W;
+  if (taps == 9 && mode == 1) { Ho = H / 2; Wo = W / 2; }
+  if (taps == 9 && mode == 2) { Ho = 2L * H; Wo = 2L * W; }
+  const long M = (long)B * Ho * Wo;
+  const int Cip = rup(Cin, 64), Cop = rup(Cout, 64);
+  const int ns = wgrad_f32_nsplit(M, Cip, Cop, taps);
+  return (long)ns * taps * Cop * Cip * 4 + (long)COLSUM_CHUNKS * Cop * 4 + 256;
+}
+
+// dm_wgrad on fp32 activations: dw (reference layout, fp32) += dy^T x patches; dbias += column sums of dy.  Split-K
+// partial slabs summed in a fixed order (bit-reproducible).
+extern "C" int dm_wgrad_f32(const dm_wgrad_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->x && a->dy && a->dw && a->workspace && a->B > 0 && (a->taps == 1 || a->taps == 9));
+  DM_REQUIRE(a->mode >= 0 && a->mode <= 2 && !a->norm_scale);
+  DM_REQUIRE(a->ws_bytes >= dm_wgrad_f32_workspace_bytes(a->B, a->H, a->W, a->Cin, a->Cout, a->taps, a->mode));
+  WgradF p{};
+  p.x = (const float*)a->x; p.ldx = a->ldx; p.dy = (const float*)a->dy; p.lddy = a->lddy;
+  p.B = a->B; p.Hi = a->H; p.Wi = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.mode = a->taps == 9 ? a->mode : 0;
+  p.taps = a->taps; p.act_silu_in = a->act_silu_in;
+  p.Ho = a->H; p.Wo = a->W;
+  if (a->taps == 9 && a->mode == 1) { p.Ho = a->H / 2; p.Wo = a->W / 2; }
+  if (a->taps == 9 && a->mode == 2) { p.Ho = 2 * a->H; p.Wo = 2 * a->W; }
+  p.M = (long)p.B * p.Ho * p.Wo;
+  p.Cip = rup(a->Cin, 64); p.Cop = rup(a->Cout, 64);
+  p.nsplit = wgrad_f32_nsplit(p.M, p.Cip, p.Cop, p.taps);
+  p.per_split = ((p.M + p.nsplit - 1) / p.nsplit + KC - 1) / KC * KC;
+  p.slab = (float*)a->workspace;
+  const int n_valid = a->n_valid > 0 ? a->n_valid : a->Cout, k_valid = a->k_valid > 0 ? a->k_valid : a->Cin;
+  hipStream_t st = (hipStream_t)stream;
+  dm_set_variant("wgrad_f32<64x64,mfma_f32_16x16x4>");
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(p.Cip / 64, p.Cop / 64, p.taps * p.nsplit), dim3(256), 0, st, p);
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_f32_reduce_kernel, dim3(ew_grid_f32((long)n_valid * k_valid * p.taps)), dim3(256), 0, st, p.slab,
+                     a->dw, p.nsplit, p.taps, p.Cop, p.Cip, n_valid, k_valid);
+  DM_LAUNCH_CHECK();
+  if (a->dbias) {
+    float* part = p.slab + (long)p.nsplit * p.taps * p.Cop * p.Cip;
+    hipLaunchKernelGGL(colsum_part_f32_kernel, dim3(COLSUM_CHUNKS), dim3(256), 0, st, p.dy, p.lddy, part, p.M, a->Cout,
+                       COLSUM_CHUNKS);
+    DM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_f32_kernel, dim3((n_valid + 255) / 256), dim3(256), 0, st, part, a->dbias, a->Cout,
+                       COLSUM_CHUNKS, n_valid, 1);
+    DM_LAUNCH_CHECK();
+  }
+  return DM_OK;
+}
+
+// out[b][c] (=|+=) sum over the batch's rows (one workgroup per batch entry, rows in order)
+extern "C" int dm_colsum_f32(const float* x, long ldx, float* out, int nbatch, int rows_per_batch, int C, int accumulate,
+                             dm_stream_t stream) {
+  DM_REQUIRE(x && out && nbatch > 0 && rows_per_batch > 0 && C > 0);
+  hipLaunchKernelGGL(colsum_batch_f32_kernel, dim3(nbatch), dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows_per_batch, C,
+                     accumulate);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_gn_silu_fwd_f32(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
+                                  void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
+                                  void* workspace, long ws_bytes, dm_stream_t stream) {
+  DM_REQUIRE(x && y && gamma && beta && stats && B > 0 && HW > 0 && G > 0 && C % G == 0);
+  (void)workspace; (void)ws_bytes;
+  hipLaunchKernelGGL(gn_fwd_f32_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, chan_add, gamma,
+                     beta, (float*)y, ldy, stats, HW, C, G, eps, act_silu);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" long dm_gn_f32_workspace_bytes(int B, int C) { return (long)B * C * 3 * 4 + 256; }
+
+extern "C" int dm_gn_silu_bwd_f32(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
+                                  const float* gamma, const float* beta, const float* stats, const void* add_in, long ldadd,
+                                  void* dx, long lddx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int act_silu,
+                                  float drop_p, unsigned long long drop_seed, float* dx_colsum, void* workspace, long ws_bytes,
+                                  dm_stream_t stream) {
+  DM_REQUIRE(x && dy && dx && gamma && beta && stats && workspace && dgamma && dbeta && G > 0 && C % G == 0);
+  DM_REQUIRE(C / G <= 128 && 256 % (C / G) == 0 && drop_p >= 0.f && drop_p < 1.f);
+  DM_REQUIRE(ws_bytes >= dm_gn_f32_workspace_bytes(B, C));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_f32_kernel, dim3(B * G), dim3(256), 0, st, (const float*)x, ldx, chan_add, (const float*)dy, lddy,
+                     gamma, beta, stats, (const float*)add_in, ldadd, (float*)dx, lddx, (float*)workspace, HW, C, G, act_silu,
+                     dm_seed32(drop_seed), dm_thresh16(drop_p), dm_inv_keep(drop_p), dx_colsum, dm_dropout_counter());
+  DM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_params_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, dgamma, dbeta,
+                     B, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+// dm_attn_fwd / dm_attn_bwd on fp32 tensors (q, k, v, o, d_o, dq, dk, dv are float*; lse / delta as in the bf16 entry
+// points: delta needs B*heads*Nq floats).  hd in {8, 16, 32, 64, 128}, any Nq / Nk >= 1.  The dropout mask is a pure
+// function of (seed, batch, head, query, key), identical in the forward and both backward kernels.
+extern "C" int dm_attn_fwd_f32(const dm_attn_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->q && a->k && a->v && (a->o || a->lse) && a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
+  AttnF p{};
+  if (fill_attn(a, p) != DM_OK) return DM_ERR_ARG;
+  dm_set_variant("attn_fwd_f32");
+  return dispatch_attn_f32(p, a->hd, 0, (hipStream_t)stream);
+}
+
+extern "C" int dm_attn_bwd_f32(const dm_attn_args* a, dm_stream_t stream) {
+  DM_REQUIRE(a && a->q && a->k && a->v && a->o && a->lse && a->d_o && a->dq && a->dk && a->dv && a->delta);
+  DM_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nk > 0);
+  AttnF p{};
+  if (fill_attn(a, p) != DM_OK) return DM_ERR_ARG;
+  dm_set_variant("attn_bwd_f32");
+  return dispatch_attn_f32(p, a->hd, 1, (hipStream_t)stream);
+}
+
+extern "C" int dm_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, long ldy, int Cpad, dm_stream_t stream) {
+  DM_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && Cpad >= C && ldy >= Cpad);
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(ew_grid_f32((long)B * HW * Cpad)), dim3(256), 0, (hipStream_t)stream, x, y, B,
+                     C, HW, ldy, Cpad);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_add_f32(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long P, int C,
+                          dm_stream_t stream) {
+  DM_REQUIRE(a && out && P > 0 && C > 0);
+  hipLaunchKernelGGL(add_f32_kernel, dim3(ew_grid_f32(P * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, P, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_silu_bwd_f32(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long P, int C,
+                               dm_stream_t stream) {
+  DM_REQUIRE(dy && x && dx && P > 0 && C > 0);
+  hipLaunchKernelGGL(silu_bwd_f32_kernel, dim3(ew_grid_f32(P * C)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, dx,
+                     lddx, P, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_film_fwd_f32(const float* h, long ldh, const float* gamma_beta, float* out, long ldo, int B, int HW, int C,
+                               float drop_p, unsigned long long drop_seed, dm_stream_t stream) {
+  DM_REQUIRE(h && gamma_beta && out && B > 0 && HW > 0 && C > 0 && drop_p >= 0.f && drop_p < 1.f);
+  hipLaunchKernelGGL(film_fwd_f32_kernel, dim3(ew_grid_f32((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, h, ldh,
+                     gamma_beta, out, ldo, (long)B * HW, HW, C, dm_seed32(drop_seed), dm_thresh16(drop_p), dm_inv_keep(drop_p),
+                     dm_dropout_counter());
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_film_bwd_f32(const float* dh, long lddh, const float* h0, long ldh, const float* gamma_beta, float* dh0,
+                               long ldo, float* dgamma, int B, int HW, int C, dm_stream_t stream) {
+  DM_REQUIRE(dh && h0 && gamma_beta && dh0 && dgamma && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(film_bwd_f32_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dh, lddh, h0, ldh, gamma_beta, dh0, ldo,
+                     dgamma, HW, C);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}

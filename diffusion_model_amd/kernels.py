@@ -14,6 +14,40 @@ from . import _lib
 from ._lib import AttnArgs, ConvArgs, Cross1Args, GemmArgs, WgradArgs, check
 
 BF16 = torch.bfloat16
+F32 = torch.float32
+# COMPUTE MODE: the dtype of the NHWC activations the host layer creates at the module boundary (nchw_to_nhwc, to_act).
+# bf16 (default) = the MFMA bf16 kernels that carry the headline; fp32 = the reference-precision mode (csrc/dm_f32.hip:
+# fp32 MFMA contractions, fp32 attention, double-accumulated GroupNorm statistics; parity bar 1e-4).  Every front-end
+# below dispatches on the dtype of the activation it is handed, so the two modes share the host code of unet.py.
+ACT = [F32 if os.environ.get("DM_COMPUTE_DTYPE", "bf16").lower() in ("fp32", "float32", "f32") else BF16]
+
+
+def set_compute_dtype(dtype) -> None:
+    """torch.bfloat16 (default) or torch.float32 (reference-precision mode).  Process-wide; switch between forwards."""
+    if isinstance(dtype, str):
+        dtype = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32, "f32": F32}[dtype.lower()]
+    if dtype not in (BF16, F32):
+        raise ValueError("compute dtype must be torch.bfloat16 or torch.float32")
+    ACT[0] = dtype
+
+
+class compute_dtype:
+    """``with compute_dtype(torch.float32): ...`` -- the mode inside the block, the previous one restored after it."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = ACT[0]
+        set_compute_dtype(self.dtype)
+
+    def __exit__(self, *exc):
+        ACT[0] = self.prev
+        return False
+
+
+def _is32(t) -> bool:
+    return t.dtype == F32
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -37,9 +71,9 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _act(t: torch.Tensor, what: str = "activation") -> int:
-    """Validate an NHWC/[M,C] bf16 activation view; return the pixel stride."""
-    if not (t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1):
-        raise ValueError(f"{what}: need a CUDA bf16 tensor with contiguous channels")
+    """Validate an NHWC/[M,C] activation view (bf16, or fp32 in the fp32 compute mode); return the pixel stride."""
+    if not (t.is_cuda and t.dtype in (BF16, F32) and t.stride(-1) == 1):
+        raise ValueError(f"{what}: need a CUDA bf16 (or fp32-mode float32) tensor with contiguous channels")
     if t.is_contiguous():  # the common case, one C call
         return t.shape[-1]
     ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
@@ -137,19 +171,37 @@ def reserve_workspace(nbytes: int, device) -> None:
 
 
 # --------------------------------------------------------------------------- weights
-def pack_weight(w: torch.Tensor, transpose: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def pack_weight(w: torch.Tensor, transpose: bool = False, out: Optional[torch.Tensor] = None, dtype=BF16) -> torch.Tensor:
     """fp32 [N,K,3,3] / [N,K,1,1] / [N,K] -> packed bf16 shadow (uint8 buffer).  transpose=True
-    builds the data-gradient operand (roles of N and K swapped, taps flipped)."""
+    builds the data-gradient operand (roles of N and K swapped, taps flipped).  dtype=float32: the fp32 mode's repack
+    (dm_pack_weight_f32: [taps][K][N] fp32, zero padded to multiples of 64)."""
     _f32(w, "weight")
     taps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
     n0, k0 = w.shape[0], w.shape[1]
     N, K = (k0, n0) if transpose else (n0, k0)
+    if dtype == F32:
+        nbytes = _lib.lib().dm_packed_weight_f32_bytes(N, K, taps)
+        if out is None:
+            out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        assert out.numel() >= nbytes
+        check(_lib.lib().dm_pack_weight_f32(_p(w), _p(out), N, K, taps, int(transpose), _stream()), "dm_pack_weight_f32")
+        return out
     nbytes = _lib.lib().dm_packed_weight_bytes(N, K, taps)
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     assert out.numel() >= nbytes
     check(_lib.lib().dm_pack_weight(_p(w), _p(out), N, K, taps, int(transpose), _stream()), "dm_pack_weight")
     return out
+
+
+def _check_pack(wp: torch.Tensor, n: int, k: int, taps: int, f32m: bool) -> None:
+    """The kernels index the packed weight by (n, k, taps) alone: a buffer packed for the OTHER compute mode (half / twice
+    the bytes) or for other sizes would be read out of bounds -- refuse it on the host."""
+    L = _lib.lib()
+    need = L.dm_packed_weight_f32_bytes(n, k, taps) if f32m else L.dm_packed_weight_bytes(n, k, taps)
+    if wp.numel() * wp.element_size() < need or (f32m and wp.numel() * wp.element_size() < need):
+        raise ValueError(f"packed weight holds {wp.numel() * wp.element_size()} bytes, the {'fp32' if f32m else 'bf16'} kernel "
+                         f"reads {need} (N={n}, K={k}, taps={taps}): packed for another compute mode or shape?")
 
 
 # --------------------------------------------------------------------------- conv / gemm
@@ -167,14 +219,24 @@ def conv3x3(x, wp, cout, *, bias=None, chan_add=None, res=None, out=None, mode=0
     Ho, Wo = (H // 2, W // 2) if mode == 1 else ((2 * H, 2 * W) if mode in (2, 3) else (H, W))
     if pool2:
         Ho, Wo = Ho // 2, Wo // 2
+    f32m = _is32(x)
     if out is None and out_f32 is None:
-        out = torch.empty((B, Ho, Wo, cout), dtype=BF16, device=x.device)
+        out = torch.empty((B, Ho, Wo, cout), dtype=x.dtype, device=x.device)
+    if f32m and pool2:
+        # fp32 mode: the nearest-x2 data-gradient = full-size convolution, then the 2x2 sums (dm_pool2_f32)
+        assert out_f32 is None and res is None and chan_add is None and drop_p == 0.0
+        full = conv3x3(x, wp, cout, bias=None, mode=mode, act_silu_in=act_silu_in, n_valid=n_valid)
+        check(_lib.lib().dm_pool2_f32(_p(full), _p(out), _act(out, "out"), B, 2 * Ho, 2 * Wo, cout, _stream()), "dm_pool2_f32")
+        if bias is not None:
+            raise ValueError("fp32 pooled data-gradient takes no bias")
+        return out
+    _check_pack(wp, cout, Cin, 9, f32m)
     a = ConvArgs()
     a.x, a.ldx, a.w = _p(x), ldx, _p(wp)
     a.bias, a.chan_add = _p(_f32(bias, "bias")), _p(_f32(chan_add, "chan_add"))
     if res is not None:
         a.res, a.ldr = _p(res), _act(res, "res")
-        assert tuple(res.shape) == (B, Ho, Wo, cout)
+        assert tuple(res.shape) == (B, Ho, Wo, cout) and res.dtype == x.dtype
     if out is not None:
         assert tuple(out.shape[:3]) == (B, Ho, Wo) and out.shape[3] >= (n_valid or cout)
         a.y, a.ldy = _p(out), _act(out, "out")
@@ -188,6 +250,10 @@ def conv3x3(x, wp, cout, *, bias=None, chan_add=None, res=None, out=None, mode=0
         sc, sh = norm_in
         assert tuple(sc.shape) == (B, Cin) and tuple(sh.shape) == (B, Cin)
         a.norm_scale, a.norm_shift = _p(_f32(sc, "norm scale")), _p(_f32(sh, "norm shift"))
+    if f32m:
+        assert norm_in is None, "GroupNorm folding is a bf16-mode option"
+        check(_lib.lib().dm_conv3x3_f32(C.byref(a), _stream()), "dm_conv3x3_f32")
+        return out if out is not None else out_f32
     pr = PROBE
     if pr is not None and mode == pr["mode"] and H == pr["H"] and Cin == pr["cin"] and cout == pr["cout"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -207,7 +273,8 @@ def gemm(x, wp, n, *, bias=None, chan_add=None, rows_per_batch=0, res=None, out=
     K = x.shape[-1]
     M = x.numel() // K
     if out is None and out_f32 is None:
-        out = torch.empty((*x.shape[:-1], n), dtype=BF16, device=x.device)
+        out = torch.empty((*x.shape[:-1], n), dtype=x.dtype, device=x.device)
+    _check_pack(wp, n, K, 1, _is32(x))
     a = GemmArgs()
     a.x, a.ldx, a.w = _p(x), ldx, _p(wp)
     a.bias, a.chan_add = _p(_f32(bias, "bias")), _p(_f32(chan_add, "chan_add"))
@@ -219,7 +286,10 @@ def gemm(x, wp, n, *, bias=None, chan_add=None, rows_per_batch=0, res=None, out=
         a.yf, a.ldyf = _p(out_f32), out_f32.stride(-2)
     a.M, a.K, a.N = M, K, n
     a.rows_per_batch, a.n_valid, a.act_silu_in = rows_per_batch, n_valid, int(act_silu_in)
-    check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
+    if _is32(x):
+        check(_lib.lib().dm_gemm_f32(C.byref(a), _stream()), "dm_gemm_f32")
+    else:
+        check(_lib.lib().dm_gemm(C.byref(a), _stream()), "dm_gemm")
     return out if out is not None else out_f32
 
 
@@ -234,7 +304,8 @@ def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0
     else:
         B, H, W = 1, 1, x.numel() // Cin
     L = _lib.lib()
-    nb = L.dm_wgrad_workspace_bytes(B, H, W, Cin, Cout, taps, mode)
+    f32m = _is32(x)
+    nb = (L.dm_wgrad_f32_workspace_bytes if f32m else L.dm_wgrad_workspace_bytes)(B, H, W, Cin, Cout, taps, mode)
     ws = workspace(nb, x.device)
     a = WgradArgs()
     a.x, a.ldx, a.dy, a.lddy, a.dw, a.dbias = _p(x), ldx, _p(dy), lddy, _p(dw), _p(dbias)
@@ -243,6 +314,10 @@ def wgrad(x, dy, dw, dbias=None, *, taps=9, mode=0, act_silu_in=False, n_valid=0
     a.workspace, a.ws_bytes = _p(ws), ws.numel()
     if norm_in is not None:
         a.norm_scale, a.norm_shift = _p(_f32(norm_in[0], "norm scale")), _p(_f32(norm_in[1], "norm shift"))
+    if f32m:
+        assert norm_in is None and dy.dtype == F32
+        check(L.dm_wgrad_f32(C.byref(a), _stream()), "dm_wgrad_f32")
+        return
     check(L.dm_wgrad(C.byref(a), _stream()), "dm_wgrad")
 
 
@@ -431,9 +506,14 @@ def gn_silu_fwd(x, gamma, beta, groups, *, chan_add=None, eps=1e-5, act=True, ou
     B = x.shape[0]
     HW = x.numel() // (B * Cc)
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
     L = _lib.lib()
+    if _is32(x):
+        check(L.dm_gn_silu_fwd_f32(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(_f32(gamma, "gamma")),
+                                   _p(_f32(beta, "beta")), _p(out), _act(out, "out"), _p(stats), B, HW, Cc, groups,
+                                   eps, int(act), None, 0, _stream()), "dm_gn_silu_fwd_f32")
+        return out, stats
     ws = workspace(L.dm_gn_workspace_bytes(B, HW, Cc, groups), x.device)
     check(L.dm_gn_silu_fwd(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(_f32(gamma, "gamma")),
                            _p(_f32(beta, "beta")), _p(out), _act(out, "out"), _p(stats), B, HW, Cc, groups,
@@ -466,8 +546,16 @@ def gn_silu_bwd(x, dy, gamma, beta, stats, groups, dgamma, dbeta, *, chan_add=No
     B = x.shape[0]
     HW = x.numel() // (B * Cc)
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     L = _lib.lib()
+    if _is32(x):
+        ws = workspace(L.dm_gn_f32_workspace_bytes(B, Cc), x.device)
+        check(L.dm_gn_silu_bwd_f32(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(dy), lddy, _p(gamma), _p(beta),
+                                   _p(_f32(stats, "stats")), _p(add_in), 0 if add_in is None else _act(add_in, "add_in"),
+                                   _p(out), _act(out, "out"), _p(_f32(dgamma, "dgamma")), _p(_f32(dbeta, "dbeta")),
+                                   B, HW, Cc, groups, int(act), float(drop_p), int(drop_seed),
+                                   _p(_f32(colsum_out, "colsum_out")), _p(ws), ws.numel(), _stream()), "dm_gn_silu_bwd_f32")
+        return out
     ws = workspace(L.dm_gn_workspace_bytes(B, HW, Cc, groups), x.device)
     check(L.dm_gn_silu_bwd(_p(x), ldx, _p(_f32(chan_add, "chan_add")), _p(dy), lddy, _p(gamma), _p(beta),
                            _p(_f32(stats, "stats")), _p(add_in), 0 if add_in is None else _act(add_in, "add_in"),
@@ -496,9 +584,12 @@ def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0, want_o=True):
     """q: [B,Nq,C], k/v: [B,Nk,C] (views into a fused qkv buffer are fine) -> (o [B,Nq,C], lse [B,heads,Nq]).
     ``want_o=False`` (one key only): just the log-sum-exp, o is returned as None (dm_hip.h)."""
     B, Nq, Cc = q.shape
-    o = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if want_o else None
+    o = torch.empty((B, Nq, Cc), dtype=q.dtype, device=q.device) if want_o else None
     lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, v, o, lse, heads, drop_p, drop_seed)
+    if _is32(q):
+        check(_lib.lib().dm_attn_fwd_f32(C.byref(a), _stream()), "dm_attn_fwd_f32")
+        return o, lse
     check(_lib.lib().dm_attn_fwd(C.byref(a), _stream()), "dm_attn_fwd")
     return o, lse
 
@@ -506,9 +597,9 @@ def attn_fwd(q, k, v, heads, *, drop_p=0.0, drop_seed=0, want_o=True):
 def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0.0, drop_seed=0, single_pass=True):
     B, Nq, Cc = q.shape
     Nk = k.shape[1]
-    dq = torch.empty((B, Nq, Cc), dtype=BF16, device=q.device) if dq is None else dq
-    dk = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dk is None else dk
-    dv = torch.empty((B, Nk, Cc), dtype=BF16, device=q.device) if dv is None else dv
+    dq = torch.empty((B, Nq, Cc), dtype=q.dtype, device=q.device) if dq is None else dq
+    dk = torch.empty((B, Nk, Cc), dtype=q.dtype, device=q.device) if dk is None else dk
+    dv = torch.empty((B, Nk, Cc), dtype=q.dtype, device=q.device) if dv is None else dv
     # scratch: rowsum(dO*O) [B,heads,Nq]; the few-token path reuses it as the [2,B,Nk,C] fp32 dK/dV reduction
     delta = torch.empty(max(B * heads * Nq, 2 * B * Nk * Cc, 32 * B * Cc if Nk == 1 else 0), dtype=torch.float32,
                         device=q.device)
@@ -516,6 +607,9 @@ def attn_bwd(q, k, v, o, lse, d_o, heads, *, dq=None, dk=None, dv=None, drop_p=0
     a.d_o, a.lddo = _p(d_o), _act(d_o, "d_o")
     a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = _p(dq), _act(dq, "dq"), _p(dk), _act(dk, "dk"), _p(dv), _act(dv, "dv")
     a.delta = _p(delta)
+    if _is32(q):
+        check(_lib.lib().dm_attn_bwd_f32(C.byref(a), _stream()), "dm_attn_bwd_f32")
+        return dq, dk, dv
     nb = _lib.lib().dm_attn_bwd_workspace_bytes(B, heads, Nq, Nk, Cc // heads)
     if nb > 0 and single_pass:   # single-pass backward: one fp32 dq partial per key split
         ws = workspace(nb, q.device)
@@ -602,11 +696,16 @@ def cross1_bwd(dy, v, w_out, heads, *, dw_out=None, drop_p=0.0, drop_seed=0):
 
 # --------------------------------------------------------------------------- layout / elementwise
 def nchw_to_nhwc(x: torch.Tensor, cpad: int = 0, out=None) -> torch.Tensor:
+    """NCHW fp32 -> NHWC in the compute mode's activation dtype (ACT), channels zero-padded to ``cpad``."""
     B, Cc, H, W = x.shape
     x = _f32(x.contiguous(), "x")
     cpad = cpad or ((Cc + 7) // 8 * 8)
     if out is None:
-        out = torch.empty((B, H, W, cpad), dtype=BF16, device=x.device)
+        out = torch.empty((B, H, W, cpad), dtype=ACT[0], device=x.device)
+    if _is32(out):
+        check(_lib.lib().dm_nchw_to_nhwc_f32(_p(x), _p(out), B, Cc, H * W, _act(out, "out"), cpad, _stream()),
+              "dm_nchw_to_nhwc_f32")
+        return out
     check(_lib.lib().dm_nchw_f32_to_nhwc_bf16(_p(x), _p(out), B, Cc, H * W, _act(out, "out"), cpad, _stream()),
           "dm_nchw_f32_to_nhwc_bf16")
     return out
@@ -623,13 +722,18 @@ def nhwc_to_nchw(x: torch.Tensor, channels: int = 0) -> torch.Tensor:
 
 
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> the compute mode's activation dtype (a cast to bf16; the tensor itself in the fp32 mode)."""
     x = _f32(x.contiguous(), "x")
+    if ACT[0] == F32:
+        return x
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
     check(_lib.lib().dm_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "dm_cast_f32_to_bf16")
     return out
 
 
 def to_f32(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == F32:
+        return x
     assert x.dtype == BF16 and x.is_contiguous()
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     check(_lib.lib().dm_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "dm_cast_bf16_to_f32")
@@ -639,8 +743,12 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 def add(a, b, out=None):
     lda = _act(a, "a")
     if out is None:
-        out = torch.empty(a.shape, dtype=BF16, device=a.device)
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
     Cc = a.shape[-1]
+    if _is32(a):
+        check(_lib.lib().dm_add_f32(_p(a), lda, _p(b), 0 if b is None else _act(b, "b"), _p(out), _act(out, "out"),
+                                    a.numel() // Cc, Cc, _stream()), "dm_add_f32")
+        return out
     check(_lib.lib().dm_add_bf16(_p(a), lda, _p(b), 0 if b is None else _act(b, "b"), _p(out), _act(out, "out"),
                                  a.numel() // Cc, Cc, _stream()), "dm_add_bf16")
     return out
@@ -648,8 +756,12 @@ def add(a, b, out=None):
 
 def silu_bwd(dy, x, out=None):
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     Cc = x.shape[-1]
+    if _is32(x):
+        check(_lib.lib().dm_silu_bwd_f32(_p(dy), _act(dy, "dy"), _p(x), _act(x, "x"), _p(out), _act(out, "out"),
+                                         x.numel() // Cc, Cc, _stream()), "dm_silu_bwd_f32")
+        return out
     check(_lib.lib().dm_silu_bwd_bf16(_p(dy), _act(dy, "dy"), _p(x), _act(x, "x"), _p(out), _act(out, "out"),
                                       x.numel() // Cc, Cc, _stream()), "dm_silu_bwd_bf16")
     return out
@@ -659,9 +771,13 @@ def film_fwd(h, gamma_beta, drop_p=0.0, drop_seed=0):
     """dropout(gamma * h + beta) for NHWC bf16 h [B, H, W, C] and fp32 rows gamma_beta [B, 2C] (unet.py:32-42,105)."""
     B, Cc = h.shape[0], h.shape[-1]
     HW = h.numel() // Cc // B
-    out = torch.empty(h.shape, dtype=BF16, device=h.device)
+    out = torch.empty(h.shape, dtype=h.dtype, device=h.device)
     gb = _f32(gamma_beta, "gamma_beta")
     assert gb.shape == (B, 2 * Cc) and gb.is_contiguous()
+    if _is32(h):
+        check(_lib.lib().dm_film_fwd_f32(_p(h), _act(h, "h"), _p(gb), _p(out), _act(out, "out"), B, HW, Cc, float(drop_p),
+                                         int(drop_seed), _stream()), "dm_film_fwd_f32")
+        return out
     check(_lib.lib().dm_film_fwd(_p(h), _act(h, "h"), _p(gb), _p(out), _act(out, "out"), B, HW, Cc, float(drop_p),
                                  int(drop_seed), _stream()), "dm_film_fwd")
     return out
@@ -671,7 +787,12 @@ def film_bwd(dh, h0, gamma_beta):
     """Returns (dh0 = gamma * dh, dgamma [B, C] fp32 = sum over pixels of dh * h0)."""
     B, Cc = h0.shape[0], h0.shape[-1]
     HW = h0.numel() // Cc // B
-    dh0 = torch.empty(h0.shape, dtype=BF16, device=h0.device)
+    dh0 = torch.empty(h0.shape, dtype=h0.dtype, device=h0.device)
+    if _is32(h0):
+        dgamma = torch.empty((B, Cc), dtype=torch.float32, device=h0.device)
+        check(_lib.lib().dm_film_bwd_f32(_p(dh), _act(dh, "dh"), _p(h0), _act(h0, "h0"), _p(_f32(gamma_beta, "gamma_beta")),
+                                         _p(dh0), _act(dh0, "dh0"), _p(dgamma), B, HW, Cc, _stream()), "dm_film_bwd_f32")
+        return dh0, dgamma
     nch = _lib.lib().dm_film_bwd_chunks(HW)
     part = torch.empty((nch, B * Cc), dtype=torch.float32, device=h0.device)
     gb = _f32(gamma_beta, "gamma_beta")
@@ -688,6 +809,10 @@ def colsum(x, out, nbatch, accumulate=False):
     """out[b][c] (+)= sum over the batch's rows of x (x: [nbatch*rows, C] view)."""
     Cc = x.shape[-1]
     rows = x.numel() // Cc // nbatch
+    if _is32(x):
+        check(_lib.lib().dm_colsum_f32(_p(x), _act(x, "x"), _p(_f32(out, "out")), nbatch, rows, Cc, int(accumulate),
+                                       _stream()), "dm_colsum_f32")
+        return out
     check(_lib.lib().dm_colsum_bf16(_p(x), _act(x, "x"), _p(_f32(out, "out")), nbatch, rows, Cc, int(accumulate),
                                     _stream()), "dm_colsum_bf16")
     return out
@@ -701,10 +826,12 @@ def batchsum(inp, out):
 def batchsum2_cast(inp, out1, out2=None, want_bf16=True):
     """out1 += sum_b inp[b]; out2 += the same (optional); returns inp as bf16 (optional) -- one launch."""
     B, Cc = inp.shape
-    cast = torch.empty((B, Cc), dtype=BF16, device=inp.device) if want_bf16 else None
-    check(_lib.lib().dm_batchsum2_cast_f32(_p(_f32(inp.contiguous(), "in")), _p(_f32(out1, "out1")),
+    inp = inp.contiguous()
+    f32m = ACT[0] == F32      # fp32 mode: the "cast" operand is the fp32 input itself
+    cast = torch.empty((B, Cc), dtype=BF16, device=inp.device) if (want_bf16 and not f32m) else None
+    check(_lib.lib().dm_batchsum2_cast_f32(_p(_f32(inp, "in")), _p(_f32(out1, "out1")),
                                            _p(_f32(out2, "out2")), _p(cast), B, Cc, _stream()), "dm_batchsum2_cast_f32")
-    return cast
+    return inp if (want_bf16 and f32m) else cast
 
 
 # --------------------------------------------------------------------------- diffusion math

@@ -76,6 +76,8 @@ class PW:
         self.n, self.k = w.shape[0], w.shape[1]
         self._fwd = self._bwd = None
         self._kf = self._kb = None
+        self._fwd32 = self._bwd32 = None     # fp32 compute mode: fp32 repacks (kernels.pack_weight(dtype=float32)),
+        self._kf32 = self._kb32 = None       # kept apart from the bf16 shadows that repack_all() rebuilds in one launch
 
     def _key(self):
         w = self.c.weight
@@ -92,6 +94,11 @@ class PW:
     @property
     def fwd(self):
         key = self._key()
+        if K.ACT[0] == torch.float32:
+            if self._kf32 != key:
+                self._fwd32 = K.pack_weight(self.c.weight.detach(), False, self._fwd32, dtype=torch.float32)
+                self._kf32 = key
+            return self._fwd32
         if self._kf != key:
             self._fwd = K.pack_weight(self.c.weight.detach(), False, self._fwd)
             self._kf = key
@@ -100,6 +107,11 @@ class PW:
     @property
     def bwd(self):
         key = self._key()
+        if K.ACT[0] == torch.float32:
+            if self._kb32 != key:
+                self._bwd32 = K.pack_weight(self.c.weight.detach(), True, self._bwd32, dtype=torch.float32)
+                self._kb32 = key
+            return self._bwd32
         if self._kb != key:
             self._bwd = K.pack_weight(self.c.weight.detach(), True, self._bwd)
             self._kb = key
@@ -336,7 +348,7 @@ class ResBlock(HipModule):
         # GroupNorm + SiLU are folded into the consuming conv (FOLD_GROUPNORM): one statistics pass over the input,
         # then the conv normalises while staging its patch; the normalised tensor is never written.  (8x8 images of
         # a batch >= 4 keep the materialised form: their four-images-per-workgroup conv tile has no folded variant.)
-        fold = FOLD_GROUPNORM[0] and not (x.shape[1] == 8 and x.shape[2] == 8 and B >= 4)
+        fold = FOLD_GROUPNORM[0] and x.dtype == BF16 and not (x.shape[1] == 8 and x.shape[2] == 8 and B >= 4)
         if fold:
             st1, n1 = K.gn_prepare(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.groups)
             h = K.conv3x3(x, PW.of(self.conv1).fwd, self.cout, bias=_b(self.conv1), chan_add=tp, drop_p=p,
@@ -523,7 +535,7 @@ class CrossAttention(HipModule):
         vc = K.gemm(ctx, PW.of(self.to_v).fwd, C)
         p = self.dropout_prob if self.training else 0.0
         seed = next(_SEED) if p > 0 else 0
-        one = ctx.shape[1] == 1 and FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C)
+        one = ctx.shape[1] == 1 and FUSE_CROSS1[0] and K.cross1_ok(self.num_heads, C) and x.dtype == BF16
         o, lse = K.attn_fwd(q, kc, vc, self.num_heads, drop_p=p, drop_seed=seed, want_o=not one)
         if one:
             # one token: same output path as the two-stream schedule (UnetLayer._fwd_attn_overlapped), so the two
@@ -555,7 +567,7 @@ class CrossAttention(HipModule):
                 self._add_dctx(g, None, dv)
             return add, None
         if fused:   # one key: dq and dk are exact zeros (dm_attn_bwd writes the same zeros); the rest runs as always
-            dq = torch.zeros((B, N, C), dtype=torch.bfloat16, device=dy.device)
+            dq = torch.zeros((B, N, C), dtype=dy.dtype, device=dy.device)
             dk = torch.zeros_like(dv)
         else:
             dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
@@ -710,12 +722,13 @@ class UnetLayer(HipModule):
         r, s_res = self.res_block._fwd(x, temb)
         dst = None if up else skip_out
         s_a = s_c = None
-        elide = has_c and ELIDE_DEAD_ATTENTION[0] and ctx.shape[1] == 1
+        bf = r.dtype == BF16   # the one-token specialisations (elision, two-stream schedule, dm_cross1) are bf16-mode kernels
+        elide = has_c and bf and ELIDE_DEAD_ATTENTION[0] and ctx.shape[1] == 1
         if elide:
             if has_a and self.attention.training and self.attention.dropout_prob > 0:
                 next(_SEED)  # keep the dropout seed sequence of the un-elided network
             xo, s_c = self.cross_attention._fwd(r, ctx, res=r, out=dst, elide=True)
-        elif has_c and OVERLAP_DEAD_ATTENTION[0] and ctx.shape[1] == 1 and (has_a or OVERLAP_CROSS_ONLY[0]):
+        elif has_c and bf and OVERLAP_DEAD_ATTENTION[0] and ctx.shape[1] == 1 and (has_a or OVERLAP_CROSS_ONLY[0]):
             xo, s_a, s_c = self._fwd_attn_overlapped(r, ctx, dst)
         elif has_a and has_c:
             xa, s_a = self.attention._fwd(r)
@@ -780,7 +793,7 @@ class UnetLayer(HipModule):
             if hasattr(self, "attention"):  # zero gradients, exactly: leave the accumulators untouched
                 g.of(self.attention.linear_qkv.weight), g.of(self.attention.linear_out.weight)
             dr = dxo  # d(xo)/d(r) is the residual branch alone
-        elif (s_c is not None and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1
+        elif (s_c is not None and dxo.dtype == BF16 and OVERLAP_DEAD_ATTENTION[0] and s_c[1].shape[1] == 1
               and (s_a is not None or OVERLAP_CROSS_ONLY[0]) and g.dctx is None):   # (a context gradient is accumulated across layers: keep that on one stream)
             # One context token: d(cross_attention)/d(its query input) is exactly 0 (dq = 0 out of a softmax over one
             # key), so the gradient that comes back through attention(r) is an exact zero and dr = dxo.  Everything
@@ -873,7 +886,7 @@ class UNET(HipModule):
         for i in range(half):
             j = L - 1 - i
             c_dec, c_skip = self.Channels[j + 1] // 2, self.Channels[i + 1]
-            cats[j] = torch.empty((B, a.shape[1], a.shape[2], c_dec + c_skip), dtype=BF16, device=dev_)
+            cats[j] = torch.empty((B, a.shape[1], a.shape[2], c_dec + c_skip), dtype=a.dtype, device=dev_)
             a, _, s = self.layers()[i]._fwd(a, temb, ctx, skip_out=cats[j][..., c_dec:])
             saved_layers.append(s)
         for i in range(half, L):
@@ -949,7 +962,7 @@ class UNET(HipModule):
             # operand needs its N (= input channels) padded to the 64-wide tile, so pad on the host
             wpad = torch.zeros((ic.weight.shape[0], x0.shape[-1], 3, 3), dtype=torch.float32, device=da.device)
             wpad[:, : self.cin] = ic.weight.detach()
-            dxp = K.conv3x3(da, K.pack_weight(wpad, True), x0.shape[-1])
+            dxp = K.conv3x3(da, K.pack_weight(wpad, True, dtype=da.dtype), x0.shape[-1])
             dx = K.nhwc_to_nchw(dxp, self.cin)
         # time MLP
         l0, l2 = self.time_mlp[0], self.time_mlp[2]

@@ -33,7 +33,8 @@ typedef void* dm_stream_t;
 
 /* ABI version / arch string ("gfx950").  Version 2 (round 2): dm_conv_args / dm_wgrad_args grew the trailing
  * norm_scale / norm_shift fields.  Version 3: dm_attn_args grew the trailing workspace / ws_bytes fields and
- * dm_attn_bwd_workspace_bytes, dm_film_fwd / dm_film_bwd were added.  Callers built against an older version must be rebuilt. */
+ * dm_attn_bwd_workspace_bytes, dm_film_fwd / dm_film_bwd were added.  Version 4 (round 3): the fp32 compute mode (the *_f32
+ * entry points at the end of this header); nothing older changed.  Callers built against an older version must be rebuilt. */
 int dm_abi_version(void);
 const char* dm_target_arch(void);
 /* Text of the HIP error behind the calling thread's last DM_ERR_LAUNCH ("" if none). */
@@ -313,6 +314,58 @@ int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, float pre_scal
 int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
                       float lr, float beta1, float beta2, float eps, float wd, int step, double ema_decay,
                       float pre_scale, int adamw, dm_stream_t stream);
+
+/* ------------------------------------------------------------------ fp32 COMPUTE MODE
+ * The reference computes in fp32 end to end (every nn.Conv2d / nn.Linear / nn.GroupNorm / SDPA of unet.py:70-356 on
+ * fp32 tensors; main_stl10.py:474-482) and the parity bar for that precision is 1e-4.  These entry points are the
+ * operators above on fp32 NHWC activations ([pixel][channel] float, pixel stride ld* in elements) with fp32 weights:
+ * contractions on v_mfma_f32_16x16x4_f32 (fp32 inputs, exact fp32 FMA chains), attention as fp32 flash-style kernels,
+ * GroupNorm statistics accumulated in double.  Same argument structs and meanings as their bf16 counterparts unless noted;
+ * every activation / gradient pointer is float*.  No channel-count or head-dim multiples are required (any Cin / Cout;
+ * hd in {8, 16, 32, 64, 128}; any Nq, Nk >= 1).  The mode exists for parity and reference-precision runs: it is general and
+ * exact, not tuned like the bf16 kernels. */
+/* fp32 weight repack [taps][round-up(K, 64)][round-up(N, 64)] (zero padded); transpose as dm_pack_weight.
+ * Replaces the weight reads of nn.Conv2d / nn.Linear (unet.py:74-75,79,113-114,160-163,225,234,261,317-320,333-335). */
+long dm_packed_weight_f32_bytes(int N, int K, int taps);
+int dm_pack_weight_f32(const float* w, float* dst, int N, int K, int taps, int transpose, dm_stream_t stream);
+/* dm_conv3x3 / dm_gemm in fp32 (unet.py:74-75,79,225-229,234,261,317-320 and their data-gradients).  Output to y (float*),
+ * or to yf when y is NULL.  pool2 and norm_scale / norm_shift are not taken (DM_ERR_ARG): the data-gradient of the
+ * nearest-x2 convolution is the full-size convolution followed by dm_pool2_f32. */
+int dm_conv3x3_f32(const dm_conv_args* args, dm_stream_t stream);
+int dm_gemm_f32(const dm_gemm_args* args, dm_stream_t stream);
+/* y[b][h][w][c] = sum of the 2x2 block of x [B, Ho, Wo, C] (contiguous): the backward of F.interpolate(nearest x2), unet.py:227. */
+int dm_pool2_f32(const float* x, float* y, long ldy, int B, int Ho, int Wo, int C, dm_stream_t stream);
+/* dm_wgrad in fp32 (the weight gradients of scaled_loss.backward(), main_stl10.py:502-503): ordered split-K, bit-reproducible. */
+long dm_wgrad_f32_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, int mode);
+int dm_wgrad_f32(const dm_wgrad_args* args, dm_stream_t stream);
+/* dm_gn_silu_fwd / dm_gn_silu_bwd in fp32 (unet.py:77-78,94,101-102,106).  Forward: workspace unused (may be NULL).
+ * Backward: workspace >= dm_gn_f32_workspace_bytes(B, C); C / G must divide 256 and be <= 128; dgamma / dbeta / dx_colsum
+ * are summed in a fixed order (bit-reproducible). */
+int dm_gn_silu_fwd_f32(const void* x, long ldx, const float* chan_add, const float* gamma, const float* beta,
+                       void* y, long ldy, float* stats, int B, int HW, int C, int G, float eps, int act_silu,
+                       void* workspace, long ws_bytes, dm_stream_t stream);
+long dm_gn_f32_workspace_bytes(int B, int C);
+int dm_gn_silu_bwd_f32(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
+                       const float* gamma, const float* beta, const float* stats, const void* add_in, long ldadd,
+                       void* dx, long lddx, float* dgamma, float* dbeta, int B, int HW, int C, int G, int act_silu,
+                       float drop_p, unsigned long long drop_seed, float* dx_colsum, void* workspace, long ws_bytes,
+                       dm_stream_t stream);
+/* F.scaled_dot_product_attention in fp32 (unet.py:119-126,136,165-172,214), forward and backward; every pointer of
+ * dm_attn_args required by the direction must be set (no NULL shortcuts); delta: B*heads*Nq floats; workspace unused. */
+int dm_attn_fwd_f32(const dm_attn_args* args, dm_stream_t stream);
+int dm_attn_bwd_f32(const dm_attn_args* args, dm_stream_t stream);
+/* Layout / elementwise helpers of the mode (unet.py:274,344,355,356; FiLM unet.py:23-42,105). */
+int dm_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, long ldy, int Cpad, dm_stream_t stream);
+int dm_add_f32(const float* a, long lda, const float* b, long ldb, float* out, long ldo, long P, int C, dm_stream_t stream);
+int dm_silu_bwd_f32(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long P, int C,
+                    dm_stream_t stream);
+int dm_colsum_f32(const float* x, long ldx, float* out, int nbatch, int rows_per_batch, int C, int accumulate,
+                  dm_stream_t stream);
+int dm_film_fwd_f32(const float* h, long ldh, const float* gamma_beta, float* out, long ldo, int B, int HW, int C,
+                    float drop_p, unsigned long long drop_seed, dm_stream_t stream);
+/* dgamma: fp32 [B, C], written (one ordered sum per (sample, channel)). */
+int dm_film_bwd_f32(const float* dh, long lddh, const float* h0, long ldh, const float* gamma_beta, float* dh0, long ldo,
+                    float* dgamma, int B, int HW, int C, dm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), f"{name} declared in include/dm_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert h.dm_abi_version() == 3 and h.dm_target_arch() == b"gfx950"
+    assert h.dm_abi_version() == 4 and h.dm_target_arch() == b"gfx950"
     # pure host helpers may be called without a GPU
     assert h.dm_packed_weight_bytes(64, 3, 9) == 64 * 64 * 9 * 2
     assert h.dm_wgrad_workspace_bytes(64, 96, 96, 64, 64, 9, 0) > 0
