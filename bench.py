@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32 = 157.3e12      # fp32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md, matrix cores table)
 TRAIN_FLOP_PER_IMG = 55.7e9   # algorithmic fwd+dgrad+wgrad FLOPs / image (reference op count)
 FWD_FLOP_PER_IMG = 18.08e9
 
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latent", action="store_true", help="skip the secondary latent-diffusion UNet leg (1 GPU only)")
     ap.add_argument("--no-elided", action="store_true", help="skip the secondary legs (dropout 0, dead-attention elided)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-compute-mode leg (1 GPU only)")
     ap.add_argument("--no-mnist", action="store_true", help="skip the MNIST small-shape leg (configs[4]; 1 GPU only)")
     ap.add_argument("--graph", action="store_true", help="run the headline steps as HIP-graph replays (single GPU)")
     ap.add_argument("--rehearse-dp", action="store_true",
@@ -530,6 +532,27 @@ def main():
             dtd = float(tt.item())
         dropout0 = {"value": imgs / dtd, "unit": "img/s", "ms_per_step": dtd / a.steps * 1e3}
 
+    # ---------------- secondary leg: the SAME optimizer step in the fp32 compute mode (reference precision: fp32 NHWC
+    # activations, fp32 MFMA contractions, fp32 attention; parity 1e-4, tests/test_gpu_fp32.py).  1 GPU only.
+    train_fp32 = None
+    if world == 1 and not a.no_fp32:
+        with K.compute_dtype(torch.float32):
+            opt_step()
+            barrier()
+            n32 = max(2, min(3, a.steps))
+            t0f = time.perf_counter()
+            for _ in range(n32):
+                loss32 = opt_step()
+            barrier()
+            dtf = time.perf_counter() - t0f
+        v32 = n32 * 2 * a.batch / dtf
+        train_fp32 = {"value": v32, "unit": "img/s", "ms_per_step": dtf / n32 * 1e3, "steps": n32, "dtype": "f32",
+                      "final_loss": float(loss32.item()),
+                      "mfma_f32_frac_algorithmic": v32 * TRAIN_FLOP_PER_IMG / PEAK_F32,
+                      "what": "same config and step in the fp32 compute mode (kernels.set_compute_dtype(torch.float32)): "
+                              "v_mfma_f32_16x16x4_f32 contractions (157.3 TFLOP/s peak), general untuned kernels -- the "
+                              "reference-precision / parity mode, not the headline"}
+
     # ---------------- secondary leg (never the headline): the same steps with unet.ELIDE_DEAD_ATTENTION on.  With the
     # one-token CLIP context the self-attention blocks and to_q / to_k cannot reach the output; skipping
     # them leaves outputs and live gradients unchanged (tests/test_gpu_train_sample.py::test_elide_dead_attention_is_exact)
@@ -657,6 +680,8 @@ def main():
     }
     if dropout0:
         out["train_dropout_0"] = dropout0
+    if train_fp32:
+        out["train_fp32"] = train_fp32
     if elided:
         out["dead_attention_elided"] = elided
     if sampling:
