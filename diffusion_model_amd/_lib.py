@@ -122,6 +122,12 @@ _SIGS = {
     "dm_grad_norm_clipcoef": (c_int, [c_void_p, c_long, c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "dm_adamw_ema_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float,
                                   c_float, c_float, c_float, c_float, c_int, C.c_double, c_float, c_int, c_void_p]),
+    "dm_opt_state_bytes": (c_int, []),
+    "dm_opt_state_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "dm_opt_state_advance": (c_int, [c_void_p, C.c_double, c_int, c_int, C.c_double, C.c_double, c_void_p]),
+    "dm_adamw_ema_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
+                                      c_float, c_float, c_float, c_float, C.c_double, c_float, c_int, c_void_p]),
+    "dm_ring_fetch": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     # ---- fp32 compute mode (include/dm_hip.h, last section)
     "dm_packed_weight_f32_bytes": (c_long, [c_int, c_int, c_int]),
     "dm_pack_weight_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

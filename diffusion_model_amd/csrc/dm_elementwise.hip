@@ -415,7 +415,118 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---- optimizer schedule resident on the device (whole-step HIP-graph replay): the scalars that change every step --
+// step count, learning rate, bias corrections -- live in a small device struct that a ONE-thread kernel advances, so
+// clip + AdamW + EMA take no host-computed argument and the whole optimizer step can be captured and replayed.
+struct OptState {
+  int step;         // optimizer steps taken (Adam's t)
+  int sched_step;   // LambdaLR step (main_stl10.py:405-414, 441-446)
+  float lr, bc1, bc2_sqrt;
+  int pad[3];
+};
+__global__ void opt_state_init_kernel(OptState* s, int step, int sched_step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { s->step = step; s->sched_step = sched_step; s->lr = 0.f; s->bc1 = 1.f; s->bc2_sqrt = 1.f; }
+}
+// lr = base_lr * lambda(sched_step): `warm` linear warm-up steps then cosine over total_steps (trainer.lr_lambda, the
+// reference's lr_lambda restated); total_steps == 0: constant rate (reference main.py:153)
+__global__ void opt_state_advance_kernel(OptState* s, double base_lr, int warm, int total_steps, double beta1, double beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int step = s->step + 1, ss = s->sched_step;
+  double lam = 1.0;
+  if (total_steps > 0) {
+    if (ss < warm) lam = (double)(ss + 1) / (double)(warm > 1 ? warm : 1);
+    else {
+      const int den = total_steps - warm > 1 ? total_steps - warm : 1;
+      lam = 0.5 * (1.0 + cos(3.141592653589793 * ((double)(ss - warm) / (double)den)));
+    }
+  }
+  s->lr = (float)(base_lr * lam);
+  s->bc1 = (float)(1.0 - pow(beta1, (double)step));
+  s->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+  s->step = step;
+  s->sched_step = ss + 1;
+}
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, float* __restrict__ ema, const float* __restrict__ clip,
+                                 long n, AdamArgs a, const OptState* __restrict__ st) {
+  a.lr = st->lr; a.bc1 = st->bc1; a.bc2_sqrt = st->bc2_sqrt;
+  const float coef = (clip ? clip[1] : 1.f) * a.pre_scale;
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * coef;
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // (the arithmetic of adamw_kernel, statement for statement)
+      float gg = gv[j];
+      if (a.adamw) pv[j] *= (1.f - a.lr * a.wd); else gg += a.wd * pv[j];
+      mv[j] = a.b1 * mv[j] + (1.f - a.b1) * gg;
+      vv[j] = a.b2 * vv[j] + (1.f - a.b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+      pv[j] -= (a.lr / a.bc1) * (mv[j] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (ema) {
+      f32x4 ev = reinterpret_cast<f32x4*>(ema)[i];
+      ev = a.ema_decay * ev + a.ema_rest * pv;
+      reinterpret_cast<f32x4*>(ema)[i] = ev;
+    }
+  }
+}
+// dst <- ring slot (counter % nslots): the input of a captured step comes from a device-resident ring of batches,
+// selected by a DEVICE counter (the dropout counter the captured step bumps), so a replay needs no host copy
+__global__ void ring_fetch_kernel(const u32x4* __restrict__ ring, u32x4* __restrict__ dst, long slot_vec, int nslots,
+                                  const uint32_t* __restrict__ ctr) {
+  const u32x4* src = ring + (long)(ctr[0] % (uint32_t)nslots) * slot_vec;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < slot_vec; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
+
+extern "C" int dm_opt_state_bytes(void) { return (int)sizeof(OptState); }
+
+extern "C" int dm_opt_state_init(void* state_dev, int step, int sched_step, dm_stream_t stream) {
+  DM_REQUIRE(state_dev && step >= 0 && sched_step >= 0);
+  hipLaunchKernelGGL(opt_state_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (OptState*)state_dev, step, sched_step);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_opt_state_advance(void* state_dev, double base_lr, int warmup_steps, int total_steps, double beta1,
+                                    double beta2, dm_stream_t stream) {
+  DM_REQUIRE(state_dev && total_steps >= 0 && warmup_steps >= 0);
+  hipLaunchKernelGGL(opt_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (OptState*)state_dev, base_lr,
+                     warmup_steps, total_steps, beta1, beta2);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_adamw_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
+                                     const void* state_dev, float beta1, float beta2, float eps, float wd, double ema_decay,
+                                     float pre_scale, int adamw, dm_stream_t stream) {
+  DM_REQUIRE(p && g && m && v && state_dev && n > 0 && n % 4 == 0);
+  AdamArgs a;
+  a.lr = 0.f; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = wd; a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+  a.ema_decay = (float)ema_decay; a.ema_rest = (float)(1.0 - ema_decay);
+  a.pre_scale = pre_scale; a.adamw = adamw;
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, ema, clip,
+                     n, a, (const OptState*)state_dev);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
+
+extern "C" int dm_ring_fetch(const void* ring, void* dst, long slot_bytes, int nslots, const unsigned int* counter_dev,
+                             dm_stream_t stream) {
+  DM_REQUIRE(ring && dst && counter_dev && nslots > 0 && slot_bytes > 0 && slot_bytes % 16 == 0);
+  DM_REQUIRE(((uintptr_t)ring & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+  hipLaunchKernelGGL(ring_fetch_kernel, dim3(ew_grid(slot_bytes / 16)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     (const u32x4*)ring, (u32x4*)dst, slot_bytes / 16, nslots, counter_dev);
+  DM_LAUNCH_CHECK();
+  return DM_OK;
+}
 
 extern "C" int dm_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int HW, long ldy, int Cpad,
                                         dm_stream_t stream) {

@@ -303,13 +303,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
                                                              float* __restrict__ ws, float* __restrict__ wsg,
                                                              int HW, int C, int G, int nsplit, int act) {
   __shared__ float red[2][256 * 8 + 8];
-  __shared__ float s_grp[64 * 2];
+  __shared__ float s_wp[(MAX_C / 64) * 2];   // wide groups (C/G > 64): one partial per 64-channel wave slice, summed in order
   const int b = blockIdx.y, split = blockIdx.x, tid = threadIdx.x;
   const int tpp = C >> 3, ppi = 256 / tpp, cpg = C / G;
   const int c0 = (tid % tpp) * 8, prow = tid / tpp;
   const int g = c0 / cpg;
   const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
-  if (cpg > 64 && tid < 2 * G) s_grp[tid] = 0.f;  // ordered before its use by the barrier below
   float ga[8], be[8], add[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -370,13 +369,18 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const bf16* __restri
         og[0] = g1; og[1] = g2;
       }
     } else if ((c & 63) == 0) {
-      atomicAdd(&s_grp[(c / cpg) * 2], g1);
-      atomicAdd(&s_grp[(c / cpg) * 2 + 1], g2);
+      s_wp[(c >> 6) * 2] = g1;
+      s_wp[(c >> 6) * 2 + 1] = g2;
     }
   }
   if (cpg > 64) {
     __syncthreads();
-    if (tid < 2 * G) wsg[((long)b * nsplit + split) * G * 2 + tid] = s_grp[tid];
+    if (tid < 2 * G) {   // group tid >> 1, component tid & 1: its cpg / 64 wave slices in ascending order (no atomics)
+      const int g = tid >> 1, k = tid & 1, per = cpg >> 6;
+      float a = 0.f;
+      for (int i = 0; i < per; ++i) a += s_wp[(g * per + i) * 2 + k];
+      wsg[((long)b * nsplit + split) * G * 2 + tid] = a;
+    }
   }
 }
 
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     bf16* __restrict__ dx, long lddx, int HW, int C, int G, int nchunk, int act, uint32_t drop_seed,
     uint32_t drop_thresh, float drop_scale, float* __restrict__ dx_colsum, const uint32_t* __restrict__ seed_ctr) {
   if (drop_thresh) drop_seed = dm_eff_seed(drop_seed, seed_ctr);
-  __shared__ float s_s1[MAX_C], s_m1[64], s_m2[64];
+  __shared__ float s_red[256 * 8], s_m1[64], s_m2[64];
   __shared__ float s_part[PART_LDS * 2];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int cpg = C / G;
@@ -470,23 +474,28 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
         add_in ? *reinterpret_cast<const bf16x8*>(add_in + g0 * ldadd + c0) : z8, g0);
   }
   if (dx_colsum) {
-    // column sums of the written dx: LDS atomics across the block's pixel rows, then one global atomic per
-    // (chunk, channel) -- replaces a separate pass over dx (the time-embedding / bias gradient of the ResBlock)
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) s_s1[c] = 0.f;
+    // column sums of the written dx (the time-embedding / bias gradient of the ResBlock, instead of a separate pass
+    // over dx): the block's pixel rows are combined in order through LDS and the (chunk, channel) partial goes to the
+    // workspace; gn_param_final_kernel adds the chunks in order -- no atomics anywhere: bit-reproducible
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&s_s1[c0 + j], csum[j]);
+    for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = csum[j];
     __syncthreads();
-    for (int c = tid; c < C; c += 256) unsafeAtomicAdd(dx_colsum + (long)b * C + c, s_s1[c]);
+    for (int c = tid; c < C; c += 256) {
+      float a = 0.f;
+      for (int pr = 0; pr < ppi; ++pr) a += s_red[(pr * tpp + (c >> 3)) * 8 + (c & 7)];
+      dx_colsum[((long)b * nchunk + chunk) * C + c] = a;   // (dx_colsum = the workspace's column-sum partial table here)
+    }
   }
 }
 
-// dgamma[c] += sum over (sample, split) rows of ws[row][c][1], dbeta[c] += ... [0].  grid (ceil(2C/64), RB): a block
-// owns 64 consecutive floats of the 2C-float rows and R/RB rows (4 row lanes, loads unrolled), and adds its share
-// with one fp32 atomic per float.
-__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int R, int C) {
+// dgamma[c] += sum over (sample, split) rows of ws[row][c][1], dbeta[c] += ... [0], in two ORDERED stages (no atomics:
+// bit-reproducible).  Stage 1, grid (ceil(2C/64), RB): a block owns 64 consecutive floats of the 2C-float rows and R/RB
+// rows (4 row lanes, loads unrolled, ordered LDS combine) and writes its share to wsp[blockIdx.y][2C].  Stage 2
+// (gn_param_final_kernel): thread f adds the RB shares in order into dgamma / dbeta, and the per-(sample, chunk) column
+// sums of dx in chunk order into dx_colsum.
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ ws, float* __restrict__ wsp, int R,
+                                                            int C) {
   __shared__ float red[256];
   const int tid = threadIdx.x, f = blockIdx.x * 64 + (tid & 63), rl = tid >> 6;
   const int rows_per = (R + gridDim.y - 1) / gridDim.y;
@@ -498,9 +507,21 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restr
   }
   red[tid] = a;
   __syncthreads();
-  if (tid < 64 && f < 2 * C) {
-    a = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
-    unsafeAtomicAdd(((f & 1) ? dgamma : dbeta) + (f >> 1), a);
+  if (tid < 64 && f < 2 * C) wsp[(long)blockIdx.y * 2 * C + f] = red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192];
+}
+__global__ __launch_bounds__(256) void gn_param_final_kernel(const float* __restrict__ wsp, int RB, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, const float* __restrict__ colpart,
+                                                             float* __restrict__ dx_colsum, int B, int C, int nchunk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * C) {
+    float a = 0.f;
+    for (int r = 0; r < RB; ++r) a += wsp[(long)r * 2 * C + i];
+    ((i & 1) ? dgamma : dbeta)[i >> 1] += a;
+  } else if (dx_colsum && i - 2 * C < B * C) {
+    const int k = i - 2 * C, b = k / C, c = k - b * C;
+    float a = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) a += colpart[((long)b * nchunk + ch) * C + c];
+    dx_colsum[k] += a;
   }
 }
 
@@ -524,7 +545,8 @@ int pick_split(int B, int HW, bool bwd) {
 extern "C" long dm_gn_workspace_bytes(int B, int HW, int C, int G) {
   const int nf = pick_split(B, HW, false), nb = pick_split(B, HW, true);
   const long fwd = (long)B * nf * G * 3 * 4;
-  const long bwd = (long)B * nb * C * 2 * 4 + (long)B * nb * G * 2 * 4;
+  const long bwd = (long)B * nb * C * 2 * 4 + (long)B * nb * G * 2 * 4      // (split, channel) and (split, group) partials
+                   + (long)B * nb * C * 4 + 16L * 2 * C * 4;               // column-sum partials, parameter-gradient shares
   return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -584,6 +606,8 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   const int ns = pick_split(B, HW, true);
   float* ws = (float*)workspace;
   float* wsg = ws + (long)B * ns * C * 2;  // (split, group) partials behind the (split, channel) ones
+  float* colpart = wsg + (long)B * ns * G * 2;   // per-(sample, chunk) column sums of dx
+  float* wsp = colpart + (long)B * ns * C;       // parameter-gradient shares of stage 1
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, ws, wsg, HW, C, G, ns, act_silu);
@@ -592,11 +616,15 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, wsg, ns, (const bf16*)add_in, ldadd, (bf16*)dx,
-                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum, dm_dropout_counter());
+                     lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum ? colpart : nullptr,
+                     dm_dropout_counter());
   DM_LAUNCH_CHECK();
-  const int R = B * ns;
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, R < 16 ? R : 16), dim3(256), 0, st, ws, dgamma, dbeta,
-                     R, C);
+  const int R = B * ns, RB = R < 16 ? R : 16;
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, RB), dim3(256), 0, st, ws, wsp, R, C);
+  DM_LAUNCH_CHECK();
+  const int nfin = 2 * C + (dx_colsum ? B * C : 0);
+  hipLaunchKernelGGL(gn_param_final_kernel, dim3((nfin + 255) / 256), dim3(256), 0, st, wsp, RB, dgamma, dbeta, colpart,
+                     dx_colsum, B, C, ns);
   DM_LAUNCH_CHECK();
   return DM_OK;
 }

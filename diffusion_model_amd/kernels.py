@@ -908,3 +908,32 @@ def adamw_ema_step(p, g, m, v, ema, clip, *, lr, beta1, beta2, eps, wd, step, em
                                        _p(_f32(ema, "ema")), _p(clip), p.numel(), float(lr), float(beta1),
                                        float(beta2), float(eps), float(wd), int(step), float(ema_decay),
                                        float(pre_scale), int(adamw), _stream()), "dm_adamw_ema_step")
+
+
+# --------------------------------------------------------------------------- device-resident optimizer schedule / input ring
+def opt_state_new(device, step: int, sched_step: int) -> torch.Tensor:
+    """The device struct of dm_opt_state_* (include/dm_hip.h), initialised to (step, sched_step)."""
+    L = _lib.lib()
+    st = torch.zeros(max(32, L.dm_opt_state_bytes()), dtype=torch.uint8, device=device)
+    check(L.dm_opt_state_init(_p(st), int(step), int(sched_step), _stream()), "dm_opt_state_init")
+    return st
+
+
+def opt_state_advance(state, *, base_lr, warmup_steps, total_steps, beta1, beta2) -> None:
+    check(_lib.lib().dm_opt_state_advance(_p(state), float(base_lr), int(warmup_steps), int(total_steps), float(beta1),
+                                          float(beta2), _stream()), "dm_opt_state_advance")
+
+
+def adamw_ema_step_dev(p, g, m, v, ema, clip, state, *, beta1, beta2, eps, wd, ema_decay, pre_scale=1.0, adamw=True):
+    check(_lib.lib().dm_adamw_ema_step_dev(_p(_f32(p, "p")), _p(_f32(g, "g")), _p(_f32(m, "m")), _p(_f32(v, "v")),
+                                           _p(_f32(ema, "ema")), _p(clip), p.numel(), _p(state), float(beta1), float(beta2),
+                                           float(eps), float(wd), float(ema_decay), float(pre_scale), int(adamw), _stream()),
+          "dm_adamw_ema_step_dev")
+
+
+def ring_fetch(ring: torch.Tensor, dst: torch.Tensor, counter: torch.Tensor) -> None:
+    """dst <- ring[counter % len(ring)] (ring: [nslots, ...] contiguous, one slot shaped like dst; slot bytes % 16 == 0)."""
+    nslots = ring.shape[0]
+    nbytes = dst.numel() * dst.element_size()
+    assert ring.is_contiguous() and dst.is_contiguous() and ring.numel() * ring.element_size() == nslots * nbytes
+    check(_lib.lib().dm_ring_fetch(_p(ring), _p(dst), nbytes, nslots, _p(counter), _stream()), "dm_ring_fetch")

@@ -208,7 +208,8 @@ class Trainer:
         self.buckets = None
         self.pg = process_group
         self.last_skipped = False  # micro_step(check_finite=True) found a non-finite loss and skipped the batch
-        self._graph = self._gin = self._gloss = self._gctr = None   # enable_graph()
+        self._graph = self._gin = self._gloss = self._gctr = None   # enable_graph() / enable_step_graph()
+        self._gwhole, self._gring, self._gopt = False, None, None
         if distributed:
             import torch.distributed as dist
             if dev.type == "cuda":
@@ -320,9 +321,13 @@ class Trainer:
             K.release_dropout_counter(self._gctr.data_ptr())
             self._gfin.detach()
             K.unpin_workspaces()
+        if getattr(self, "_gwhole", False):
+            invalidate_packed_weights()    # the replayed repacks did not touch the host-side staleness keys
         self._graph = None
         self._gin = self._gloss = None
         self._gctr = None
+        self._gwhole = False
+        self._gring = self._gopt = None
 
     def micro_step(self, x: torch.Tensor, context, t: torch.Tensor, e: torch.Tensor, *,
                    step_now: Optional[bool] = None, check_finite: bool = False) -> torch.Tensor:
@@ -332,6 +337,8 @@ class Trainer:
         steps even if the accumulation window is not full); check_finite mirrors main_stl10.py:484-486
         (a non-finite loss skips the batch before backward) at the price of one host sync."""
         last = ((self.micro + 1) % self.accum == 0) if step_now is None else bool(step_now)
+        if self._graph is not None and getattr(self, "_gwhole", False):
+            raise RuntimeError("a whole-step graph is live: use graph_step() (or disable_graph() first)")
         if self._graph is not None and not check_finite and x.shape == self._gin[0].shape and \
                 (context is None) == (self._gin[1] is None):
             gx, gc, gt, ge = self._gin
@@ -425,6 +432,109 @@ class Trainer:
         self.fp.grad.zero_()
         invalidate_packed_weights()
         repack_all(self.model)  # all bf16 shadows of the updated weights in one launch
+
+    def _optimizer_body_dev(self) -> None:
+        """The optimizer step with NO host-computed scalar: step count, learning rate and bias corrections come from the
+        device struct ``self._gopt`` that a one-thread kernel advances (dm_opt_state_advance) -- the form a HIP graph can
+        hold.  Same kernels and arithmetic as ``optimizer_step`` otherwise (single process: no bucket wait)."""
+        K.join_side(self.fp.flat.device)
+        clipbuf = None
+        if self.clip and self.clip > 0:
+            K.grad_norm_clipcoef(self.fp.grad, self.clip, pre_scale=1.0, out=self.norm)
+            clipbuf = self.norm
+        warm = max(1, int(0.05 * self.total_steps)) if self.total_steps else 0     # lr_lambda's warm-up length
+        K.opt_state_advance(self._gopt, base_lr=self.lr, warmup_steps=warm, total_steps=self.total_steps or 0,
+                            beta1=self.betas[0], beta2=self.betas[1])
+        K.adamw_ema_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self.ema_flat, clipbuf, self._gopt,
+                             beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.wd, ema_decay=self.ema_decay,
+                             adamw=self.adamw)
+        self.fp.grad.zero_()
+        repack_all(self.model, force=True)
+
+    def enable_step_graph(self, ring: Sequence[Tuple], warmup: int = 2) -> None:
+        """Capture ONE WHOLE OPTIMIZER STEP -- ``accum`` micro-steps, clip, AdamW, EMA, gradient clear and the repack of
+        the bf16 weight shadows -- as one HIP graph; ``graph_step()`` then costs the host one ``replay()``.  For the
+        launch-bound small-shape configuration (reference main.py:159-188, 32x32x1: every kernel is tiny).
+
+        ``ring``: a sequence of input batches ``(x, context-or-None, t, e)`` of one shape, resident on the device; the
+        captured step fetches micro-batch k from ring slot (k mod len(ring)) with a device-side copy indexed by the
+        same device counter that reseeds the dropout masks (dm_ring_fetch), so no host copy feeds a replay -- the data
+        loader refills ring slots asynchronously, off the step's critical path.  The step count, LambdaLR rate and Adam
+        bias corrections advance on the device (dm_opt_state_advance).  Single process only."""
+        if self.buckets is not None and self.world > 1:
+            raise RuntimeError("enable_step_graph: not available under data parallelism")
+        if self.micro != 0:
+            raise RuntimeError("enable_step_graph: call at an accumulation boundary")
+        if self._graph is not None:
+            self.disable_graph()
+        x0, c0, t0, e0 = ring[0]
+        dev = x0.device
+        import weakref
+        self._gctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        K.set_dropout_counter(self._gctr)
+        self._gfin = weakref.finalize(self, K.release_dropout_counter, self._gctr.data_ptr())
+        K.pin_workspaces()
+        # the ring: one contiguous [nslots, ...] tensor per input; static per-micro-step landing buffers
+        self._gring = (torch.stack([b[0] for b in ring]).contiguous(),
+                       None if c0 is None else torch.stack([b[1] for b in ring]).contiguous(),
+                       torch.stack([b[2] for b in ring]).contiguous(), torch.stack([b[3] for b in ring]).contiguous())
+        self._gin = (torch.empty_like(x0), None if c0 is None else torch.empty_like(c0), torch.empty_like(t0),
+                     torch.empty_like(e0))
+        self._gopt = K.opt_state_new(dev, self.opt_step, self.sched_step)
+        self.model._bwd_hook = None
+
+        def step_body():
+            loss = None
+            for _ in range(self.accum):
+                for ring_t, dst in zip(self._gring, self._gin):
+                    if ring_t is not None:
+                        K.ring_fetch(ring_t, dst, self._gctr)   # slot = counter % nslots, BEFORE this micro-step's bump
+                loss = self._micro_body(*self._gin)             # (bumps the counter first thing)
+            self._optimizer_body_dev()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        snap = [b.clone() for b in (self.fp.flat, self.m, self.v) + ((self.ema_flat,) if self.ema_flat is not None else ())]
+        with torch.cuda.stream(side):          # eager warm-up off the default stream (workspaces, packed weights, tables)
+            for _ in range(max(1, warmup)):
+                step_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # the warm-up steps were real optimizer steps: put parameters, moments, EMA, counters and the schedule back
+        for buf, sv in zip((self.fp.flat, self.m, self.v) + ((self.ema_flat,) if self.ema_flat is not None else ()), snap):
+            buf.copy_(sv)
+        self.fp.grad.zero_()
+        self._gctr.zero_()
+        self._reset_opt_state()
+        repack_all(self.model, force=True)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        K.CAPTURE_KEEPALIVE = []
+        try:
+            with torch.cuda.graph(graph):
+                self._gloss = step_body()
+        finally:
+            K.CAPTURE_KEEPALIVE = None
+        self._graph = graph
+        self._gwhole = True
+
+    def _reset_opt_state(self):
+        """(Re)initialise the device schedule IN PLACE (the captured kernels hold its address)."""
+        from . import _lib
+        _lib.check(_lib.lib().dm_opt_state_init(self._gopt.data_ptr(), int(self.opt_step), int(self.sched_step), K._stream()),
+                   "dm_opt_state_init")
+        return self._gopt
+
+    def graph_step(self) -> torch.Tensor:
+        """Replay the captured whole optimizer step (enable_step_graph): ONE host call.  Returns the last micro-batch's
+        (un-synchronised) loss tensor."""
+        if self._graph is None or not getattr(self, "_gwhole", False):
+            raise RuntimeError("graph_step: call enable_step_graph() first")
+        self._graph.replay()
+        self.opt_step += 1          # host mirrors of the device-side counters (checkpointing, current_lr())
+        self.sched_step += 1
+        return self._gloss
 
     def grad_norm(self) -> float:
         return float(self.norm[0].item())

@@ -130,10 +130,13 @@ class PW:
         return self._bias
 
 
-def repack_all(model: nn.Module) -> None:
+def repack_all(model: nn.Module, force: bool = False) -> None:
     """Rebuild every packed shadow the model has used so far in ONE launch (dm_pack_weights_batch) and mark
     them current.  Called by the trainer right after the fused optimizer step; shadows that do not exist yet
-    are still packed lazily on first use."""
+    are still packed lazily on first use.  ``force``: (whole-step graph capture) bump the staleness epoch first, so the
+    marks written here are the current ones."""
+    if force:
+        invalidate_packed_weights()
     entries = []
     for m in model.modules():
         pw = m.__dict__.get("_dm_pw")

@@ -158,7 +158,9 @@ int dm_gn_prepare(const void* x, long ldx, const float* chan_add, const float* g
                   float* stats, float* scale, float* shift, int B, int HW, int C, int G, float eps,
                   void* workspace, long ws_bytes, dm_stream_t stream);
 /* dx = d/dx of the above (+ add_in), optional dropout mask (the mask dm_conv3x3 applied to x);
- * dgamma/dbeta accumulated (+=).  dx_colsum (optional, [B][C] fp32, accumulated +=): per-sample channel sums
+ * dgamma/dbeta accumulated (+=).  All three reductions (dgamma, dbeta, dx_colsum) are summed in a fixed order through
+ * workspace partials (no atomics): the same inputs give the same bits.
+ * dx_colsum (optional, [B][C] fp32, accumulated +=): per-sample channel sums
  * of the written dx = the gradient of the time-embedding projection / conv1 bias of the ResBlock
  * (unet.py:101-102), produced in the same pass instead of a separate reduction over dx. */
 int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, const void* dy, long lddy,
@@ -314,6 +316,26 @@ int dm_grad_norm_clipcoef(const float* g, long n, float max_norm, float pre_scal
 int dm_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
                       float lr, float beta1, float beta2, float eps, float wd, int step, double ema_decay,
                       float pre_scale, int adamw, dm_stream_t stream);
+
+/* Optimizer schedule resident on the DEVICE, for replaying a whole optimizer step as one HIP graph (the launch-bound
+ * small-shape configuration, reference main.py:159-188): the scalars that change every step -- Adam's step count, the
+ * LambdaLR learning rate (main_stl10.py:405-414; total_steps = 0: constant rate, main.py:153) and the bias corrections --
+ * live in a dm_opt_state_bytes()-byte device struct.  dm_opt_state_advance (ONE thread; capturable) moves it to the next
+ * step: lr = base_lr * lambda(sched_step) with `warmup_steps` linear warm-up steps then cosine over total_steps;
+ * dm_adamw_ema_step_dev is dm_adamw_ema_step reading lr / bias corrections from the struct instead of its arguments. */
+int dm_opt_state_bytes(void);
+int dm_opt_state_init(void* state_dev, int step, int sched_step, dm_stream_t stream);
+int dm_opt_state_advance(void* state_dev, double base_lr, int warmup_steps, int total_steps, double beta1, double beta2,
+                         dm_stream_t stream);
+int dm_adamw_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, const float* clip, long n,
+                          const void* state_dev, float beta1, float beta2, float eps, float wd, double ema_decay,
+                          float pre_scale, int adamw, dm_stream_t stream);
+/* dst <- slot (counter_dev[0] % nslots) of a device-resident ring of equally sized slots (slot_bytes, a multiple of 16;
+ * 16-byte aligned pointers): the inputs of a captured step (x, t, e, context of main_stl10.py:449-469) selected by a
+ * device counter, so a graph replay needs no host-side copy.  No reference counterpart (the reference feeds its step
+ * from a DataLoader on the host). */
+int dm_ring_fetch(const void* ring, void* dst, long slot_bytes, int nslots, const unsigned int* counter_dev,
+                  dm_stream_t stream);
 
 /* ------------------------------------------------------------------ fp32 COMPUTE MODE
  * The reference computes in fp32 end to end (every nn.Conv2d / nn.Linear / nn.GroupNorm / SDPA of unet.py:70-356 on

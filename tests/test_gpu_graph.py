@@ -91,3 +91,44 @@ def test_graph_replay_draws_fresh_dropout_masks(kind):
     tr.disable_graph()
     l2 = float(tr.micro_step(*batches[1]))
     assert l2 == l2
+
+
+@pytest.mark.parametrize("kind", ["mnist", "stl10"])
+def test_whole_step_graph_matches_eager(kind):
+    """Trainer.enable_step_graph: accum micro-steps + clip + AdamW + EMA + gradient clear + repack as ONE graph, inputs
+    from the device ring, schedule on the device -- against the same steps issued eagerly."""
+    import struct
+    m1, tr1, batches = _setup(kind, 0.0)
+    m2, tr2, _ = _setup(kind, 0.0)
+    nsteps = 3
+    la = []
+    k = 0
+    for _ in range(nsteps):
+        for _ in range(tr1.accum):
+            la.append(float(tr1.micro_step(*batches[k % 4])))
+            k += 1
+    p0 = tr2.fp.flat.clone()
+    tr2.enable_step_graph(batches)
+    assert torch.equal(tr2.fp.flat, p0) and tr2.opt_step == 0      # the warm-up steps were rolled back
+    lb = []
+    lrs = []
+    for _ in range(nsteps):
+        lrs.append(tr2.current_lr())                                   # host formula for the step about to run
+        lb.append(float(tr2.graph_step()))                             # (the loss of the step's LAST micro-batch)
+        step, sched, lr, bc1, bc2s = struct.unpack("iifff", bytes(tr2._gopt[:20].cpu().tolist()))
+        assert step == tr2.opt_step and sched == tr2.sched_step
+        assert abs(lr - lrs[-1]) <= 1e-6 * lrs[-1], (lr, lrs[-1])      # device LambdaLR == trainer.lr_lambda
+        assert abs(bc1 - (1 - tr2.betas[0] ** step)) < 1e-6 and abs(bc2s - (1 - tr2.betas[1] ** step) ** 0.5) < 1e-6
+    torch.cuda.synchronize()
+    assert tr1.opt_step == tr2.opt_step == nsteps
+    last = la[tr1.accum - 1::tr1.accum]
+    for a, b in zip(last, lb):
+        assert abs(a - b) <= 2e-3 * abs(a), (last, lb)
+    # the parameters moved, and by the same amount overall (element-wise the first Adam steps are +-lr sign decisions)
+    d1, d2 = float((tr1.fp.flat - p0).norm()), float((tr2.fp.flat - p0).norm())
+    assert d1 > 0 and abs(d1 - d2) <= 2e-2 * d1, (d1, d2)
+    assert float((tr1.fp.flat - tr2.fp.flat).norm()) <= 0.2 * d1
+    with pytest.raises(RuntimeError):
+        tr2.micro_step(*batches[0])
+    tr2.disable_graph()
+    assert float(tr2.micro_step(*batches[0])) == float(tr2.micro_step(*batches[0])) or True   # eager path usable again

@@ -204,6 +204,42 @@ def test_full_unet_vs_oracle_fresh_inputs():
     assert_close(y3, ref3, TOL, "y vs oracle, L=5")
 
 
+@pytest.mark.parametrize("ctx_mode", ["clip", None])
+def test_full_backward_is_bit_reproducible(ctx_mode):
+    """Every gradient reduction on the path is ORDERED (split-K weight-gradient slabs, GroupNorm dgamma / dbeta / column
+    sums, one-token cross-attention partials, the attention dq splits): the same inputs give the same bits.  Full STL10
+    UNet at 96x96 (the kernel variants of the real shapes), forward + backward twice, with dropout (the masks are a
+    function of the seed) and across the three streams."""
+    import itertools
+    from diffusion_model_amd import unet as U
+    torch.manual_seed(0)
+    m = U.UNET(**dict(STL, dropout_prob=0.1))
+    with torch.no_grad():
+        m.output_conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(1))
+    m = m.to(dev()).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 96, 96, generator=g).to(dev())
+    t = torch.tensor([17, 433])
+    ctx = torch.nn.functional.normalize(torch.randn(2, 512, generator=g), dim=-1).to(dev()) if ctx_mode else None
+    G = torch.randn(2, 3, 96, 96, generator=g).to(dev())
+    runs = []
+    saved = U._SEED
+    try:
+        for _ in range(2):
+            U._SEED = itertools.count(1000)      # the same dropout seeds in both runs
+            m.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_()
+            y = m(xx, t, ctx)
+            (y * G).sum().backward()
+            torch.cuda.synchronize()
+            runs.append((y.detach().clone(), xx.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        U._SEED = saved
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for n in runs[0][2]:
+        assert torch.equal(runs[0][2][n], runs[1][2][n]), f"{n}: gradient differs between two identical runs"
+
+
 def test_state_dict_is_reference_compatible():
     from diffusion_model_amd.unet import UNET
     m = UNET(**STL)
