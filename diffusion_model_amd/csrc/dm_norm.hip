@@ -245,15 +245,113 @@ __global__ __launch_bounds__(OP_THREADS) void gn_onepass_fwd_kernel(const bf16* 
     }
   }
 }
+// HALF-CU form of the same one-pass kernel: 512 threads at <= 128 VGPRs (4 waves per SIMD), so a workgroup is half a CU's
+// register file and a workgroup of another stream -- or a second one of these -- runs beside it (the whole-CU form above
+// time-slices with the other streams of the training step).  MAXP pieces per thread, instantiated per slab size (5 / 9 / 18:
+// the UNet's 256ch@24x24, 128ch@48x48, 256ch@48x48) so that a small slab does not pay the largest one's registers.  The slab
+// is addressed through buffer descriptors over the sample: ONE per-lane byte offset plus a scalar offset per piece (the
+// pieces of a thread are a constant pixel stride apart) instead of MAXP 64-bit addresses, and a piece past the sample's
+// last pixel is out of range -- the hardware returns zeros for the load and drops the store.
+constexpr int OP2_THREADS = 512;
+template <int MAXP>
+__global__ __launch_bounds__(OP2_THREADS, 4) void gn_onepass2_fwd_kernel(const bf16* __restrict__ x, long ldx,
+                                                                          const float* __restrict__ chan_add,
+                                                                          const float* __restrict__ gamma,
+                                                                          const float* __restrict__ beta,
+                                                                          float* __restrict__ stats, bf16* __restrict__ y, long ldy,
+                                                                          int B, int HW, int C, float eps, int act) {
+  constexpr int T = OP2_THREADS;
+  __shared__ Wf red[T / 64];
+  __shared__ float s_ms[2];
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3, g = jj & 7, b = (jj >> 3) * 8 + xcd;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cpg = C >> 3, ppp = cpg >> 3;          // channels per group; 16-byte pieces per pixel of this group
+  const int sub = tid % ppp, c0 = g * cpg + sub * 8;
+  const int pix0 = tid / ppp, pstep = T / ppp;      // piece k of this thread: pixel pix0 + k * pstep
+  float add[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) add[j] = chan_add ? chan_add[(long)b * C + c0 + j] : 0.f;
+  const int xbytes = (int)((((long)HW - 1) * ldx + C) * 2), ybytes = (int)((((long)HW - 1) * ldy + C) * 2);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * HW * ldx), 0, xbytes, 0x00020000);
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (long)b * HW * ldy), 0, ybytes, 0x00020000);
+  const int vx = (int)((pix0 * ldx + c0) * 2), vy = (int)((pix0 * ldy + c0) * 2);
+  const int sx = (int)(pstep * ldx * 2), sy = (int)(pstep * ldy * 2);
+  u32x4 v[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx, k * sx, 0));
+  float s = 0.f, ss = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    if (pix0 + k * pstep < HW) {
+      const bf16x8 h = __builtin_bit_cast(bf16x8, v[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)h[j] + add[j];
+        s += f; ss += f * f;
+      }
+      cnt += 8.f;
+    }
+  }
+  Wf w;
+  w.n = cnt;
+  w.mean = cnt > 0.f ? s / cnt : 0.f;
+  w.m2 = cnt > 0.f ? fmaxf(ss - s * w.mean, 0.f) : 0.f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Wf t;
+    t.n = __shfl_xor(w.n, o, 64); t.mean = __shfl_xor(w.mean, o, 64); t.m2 = __shfl_xor(w.m2, o, 64);
+    w = wf_merge(w, t);
+  }
+  if (lane == 0) red[wave] = w;
+  __syncthreads();
+  if (tid == 0) {
+    Wf acc = red[0];
+    for (int i = 1; i < T / 64; ++i) acc = wf_merge(acc, red[i]);
+    const float rstd = rsqrtf(acc.m2 / acc.n + eps);
+    s_ms[0] = acc.mean; s_ms[1] = rstd;
+    if (stats) { stats[((long)b * 8 + g) * 2] = acc.mean; stats[((long)b * 8 + g) * 2 + 1] = rstd; }
+  }
+  __syncthreads();
+  const float mean = s_ms[0], rstd = s_ms[1];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = gamma[c0 + j] * rstd;
+    sh[j] = beta[c0 + j] + (add[j] - mean) * sc[j];
+  }
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    if (pix0 + k * pstep < HW) {
+      const bf16x8 h = __builtin_bit_cast(bf16x8, v[k]);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = (float)h[j] * sc[j] + sh[j];
+        o[j] = (bf16)(act ? dm_silu(z) : z);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(ry, 0, 0, 0)), o),
+                                             ry, vy, k * sy, 0);
+    }
+  }
+}
+int gn_onepass_mode() {   // 0: two passes, 1: whole-CU one pass, 2: half-CU one pass (the default for 16-channel groups and wider)
+  const char* e = getenv("DM_GN_ONEPASS");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+}
 bool gn_onepass_ok(int HW, int C, int G) {
   // OPT-IN (DM_GN_ONEPASS=1; read per call: tests switch it at run time).  Alone the kernel beats the two passes (table
   // below), but its workgroup is a whole CU's registers (1024 threads x 126 VGPRs), so inside the step it cannot share a
   // CU with the other streams' workgroups and waits for CUs to drain: training step and sampling measured equal at best
   // (14.52 vs 14.52 ms, 28.2 vs 28.3 img/s), its kernel time in the sampling loop 265 us on average (max 1.36 ms) against
   // ~100 us for the pair; capped at 64 VGPRs (two workgroups per CU) it spills and loses outright (15.38 vs 15.22 ms).
-  const char* e = getenv("DM_GN_ONEPASS");
-  const bool on = e && e[0] == '1';
+  const int mode = gn_onepass_mode();
+  const bool on = mode != 0;
   const int cpg = G > 0 ? C / G : 0;
+  if (mode == 2) {   // half-CU form: up to 18 pieces per thread of a 512-thread workgroup
+    static const int min_cpg = [] { const char* e = getenv("DM_GN_ONEPASS_MINCPG"); return e ? atoi(e) : 16; }();   // developer switch
+    return G == 8 && cpg >= min_cpg && cpg % 8 == 0 && OP2_THREADS % (cpg / 8) == 0 && (long)HW * (cpg / 8) <= (long)OP2_THREADS * 18;
+  }
   // 16-channel groups and wider (32-byte pieces and up).  With 8-channel groups (64 channels) a slab is a 16-byte piece
   // of every 128-byte pixel row and the strided stream loses: 64ch@96x96, B=64: 55.7 us against 44.9 us in two passes;
   // 128ch@48x48 30.4 -> 24.0 us, 256ch@24x24 19.5 -> 14.2, 256ch@48x48 44.7 -> 34.9 (tools/hbmbench.py).
@@ -560,9 +658,20 @@ extern "C" int dm_gn_silu_fwd(const void* x, long ldx, const float* chan_add, co
   const int ns = pick_split(B, HW, false);
   hipStream_t st = (hipStream_t)stream;
   if (gn_onepass_ok(HW, C, G)) {
-    dm_set_variant("gn_onepass_fwd");
-    hipLaunchKernelGGL(gn_onepass_fwd_kernel, dim3(((B + 7) / 8) * 64), dim3(OP_THREADS), 0, st, (const bf16*)x, ldx,
-                       chan_add, gamma, beta, stats, (bf16*)y, ldy, B, HW, C, eps, act_silu);
+    if (gn_onepass_mode() == 2) {
+      const long pieces = ((long)HW * (C / G / 8) + OP2_THREADS - 1) / OP2_THREADS;
+      const dim3 grid(((B + 7) / 8) * 64), blk(OP2_THREADS);
+#define DM_OP2(P) hipLaunchKernelGGL((gn_onepass2_fwd_kernel<P>), grid, blk, 0, st, (const bf16*)x, ldx, chan_add, gamma, beta, \
+                                     stats, (bf16*)y, ldy, B, HW, C, eps, act_silu)
+      if (pieces <= 5) { dm_set_variant("gn_onepass2_fwd<5>"); DM_OP2(5); }
+      else if (pieces <= 9) { dm_set_variant("gn_onepass2_fwd<9>"); DM_OP2(9); }
+      else { dm_set_variant("gn_onepass2_fwd<18>"); DM_OP2(18); }
+#undef DM_OP2
+    } else {
+      dm_set_variant("gn_onepass_fwd");
+      hipLaunchKernelGGL(gn_onepass_fwd_kernel, dim3(((B + 7) / 8) * 64), dim3(OP_THREADS), 0, st,
+                         (const bf16*)x, ldx, chan_add, gamma, beta, stats, (bf16*)y, ldy, B, HW, C, eps, act_silu);
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
   }

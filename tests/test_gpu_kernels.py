@@ -484,26 +484,40 @@ def test_gn_onepass_forward_full_size_and_dispatch(K, monkeypatch):
     at a slab of the maximum size (256 channels @ 48x48: nine pieces per thread), with more than eight samples (two
     rounds of the sample -> XCD placement), a channel-add and an output that is a slice of a wider buffer; 64-channel
     tensors (8-channel groups) must keep the two-pass kernels.  Both against fp32 torch, and against each other."""
-    monkeypatch.setenv("DM_GN_ONEPASS", "1")   # opt-in: a whole-CU workgroup does not pay inside the multi-stream step
     B, H, C = 9, 48, 256
     x = q16(rnd(B, C, H, H, seed=1) * 1.3 - 0.2)
     gamma, beta, ca = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, seed=4)
     ref = F.silu(F.group_norm(x + ca[:, :, None, None], 8, gamma, beta, 1e-5))
-    buf = torch.full((B, H, H, 2 * C), 3.0, dtype=torch.bfloat16, device=dev())
-    y, stats = K.gn_silu_fwd(nhwc(x), gamma, beta, 8, chan_add=ca, out=buf[..., C:])
-    assert K.last_variant() == "gn_onepass_fwd"
-    assert_close(nchw(buf[..., C:].contiguous()), ref, BF, "one-pass gn fwd")
-    assert float((buf[..., :C].float() - 3.0).abs().max()) == 0.0
     xg = (x + ca[:, :, None, None]).view(B, 8, -1)
-    assert_close(stats[..., 0], xg.mean(-1), 1e-4, "mean", atol_frac=1e-4)
-    assert_close(stats[..., 1], torch.rsqrt(xg.var(-1, unbiased=False) + 1e-5), 1e-4, "rstd")
-    K.gn_silu_fwd(nhwc(q16(rnd(2, 64, 16, 16, seed=5))), torch.ones(64, device=dev()), torch.zeros(64, device=dev()), 8)
-    assert K.last_variant() == "gn_stats+gn_apply"
-    monkeypatch.delenv("DM_GN_ONEPASS")        # the default: two passes for every width
+    monkeypatch.setenv("DM_GN_ONEPASS", "0")   # the two-pass pair
     y2, stats2 = K.gn_silu_fwd(nhwc(x), gamma, beta, 8, chan_add=ca)
     assert K.last_variant() == "gn_stats+gn_apply"
-    assert_close(y2.float(), buf[..., C:].float(), BF, "two-pass vs one-pass")
-    assert_close(stats2, stats, 1e-5, "two-pass vs one-pass statistics", atol_frac=1e-6)
+    # mode 1: the whole-CU workgroup (opt-in); default (unset) = mode 2: the half-CU workgroup, 18 / 9 / 5 pieces per thread
+    for mode, variant in (("1", "gn_onepass_fwd"), (None, "gn_onepass2_fwd<18>")):
+        if mode is None:
+            monkeypatch.delenv("DM_GN_ONEPASS")
+        else:
+            monkeypatch.setenv("DM_GN_ONEPASS", mode)
+        buf = torch.full((B, H, H, 2 * C), 3.0, dtype=torch.bfloat16, device=dev())
+        y, stats = K.gn_silu_fwd(nhwc(x), gamma, beta, 8, chan_add=ca, out=buf[..., C:])
+        assert K.last_variant() == variant
+        assert_close(nchw(buf[..., C:].contiguous()), ref, BF, "one-pass gn fwd " + variant)
+        assert float((buf[..., :C].float() - 3.0).abs().max()) == 0.0
+        assert_close(stats[..., 0], xg.mean(-1), 1e-4, "mean", atol_frac=1e-4)
+        assert_close(stats[..., 1], torch.rsqrt(xg.var(-1, unbiased=False) + 1e-5), 1e-4, "rstd")
+        assert_close(y2.float(), buf[..., C:].float(), BF, "two-pass vs one-pass")
+        assert_close(stats2, stats, 1e-5, "two-pass vs one-pass statistics", atol_frac=1e-6)
+        K.gn_silu_fwd(nhwc(q16(rnd(2, 64, 16, 16, seed=5))), torch.ones(64, device=dev()), torch.zeros(64, device=dev()), 8)
+        assert K.last_variant() == "gn_stats+gn_apply"      # 8-channel groups keep the two passes
+    # the smaller instantiations of the default form, a ragged pixel count (piece validity), no activation
+    for (Bs, Hs, Ws, Cs), variant in (((3, 24, 24, 256), "gn_onepass2_fwd<5>"), ((2, 48, 48, 128), "gn_onepass2_fwd<9>"),
+                                      ((2, 5, 7, 128), "gn_onepass2_fwd<5>"), ((2, 40, 33, 256), "gn_onepass2_fwd<18>")):
+        xs = q16(rnd(Bs, Cs, Hs, Ws, seed=Cs + Hs) * 0.8 + 0.1)
+        gs, bs = 1 + 0.1 * rnd(Cs, seed=6), 0.1 * rnd(Cs, seed=7)
+        ys, _ = K.gn_silu_fwd(nhwc(xs), gs, bs, 8, act=(Hs != 5))
+        assert K.last_variant() == variant
+        r = F.group_norm(xs, 8, gs, bs, 1e-5)
+        assert_close(nchw(ys), F.silu(r) if Hs != 5 else r, BF, variant)
 
 
 def test_gn_silu_bwd_fused_column_sums():
