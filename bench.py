@@ -551,6 +551,34 @@ def main():
             dtd = float(tt.item())
         dropout0 = {"value": imgs / dtd, "unit": "img/s", "ms_per_step": dtd / a.steps * 1e3}
 
+    # ---------------- secondary leg: the same step with context=None (reference inference_sweeps.py:110-115 /
+    # Classifier_Guidance.py:177-181 style models): no cross-attention runs, so the self-attention blocks are LIVE --
+    # their output reaches the loss (under the one-token CLIP context they are provably dead)
+    train_live_attention = None
+    if not a.no_elided:
+        def opt_step_noctx():
+            loss = None
+            for i in range(2):
+                x_, _, t_, e_ = data.draw(i)
+                loss = tr.micro_step(x_, None, t_, e_)
+            return loss
+        for _ in range(2):
+            opt_step_noctx()
+        barrier()
+        t0n = time.perf_counter()
+        for _ in range(a.steps):
+            lossn = opt_step_noctx()
+        barrier()
+        dtn = time.perf_counter() - t0n
+        if world > 1:
+            tt = torch.tensor([dtn], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtn = float(tt.item())
+        train_live_attention = {"value": imgs / dtn, "unit": "img/s", "ms_per_step": dtn / a.steps * 1e3,
+                                "final_loss": float(lossn.item()),
+                                "what": "same optimizer step with context=None: cross-attention absent, the 48x48 and 24x24 "
+                                        "self-attention blocks live (their gradients reach the loss)"}
+
     # ---------------- secondary leg: the SAME optimizer step in the fp32 compute mode (reference precision: fp32 NHWC
     # activations, fp32 MFMA contractions, fp32 attention; parity 1e-4, tests/test_gpu_fp32.py).  1 GPU only.
     train_fp32 = None
@@ -701,6 +729,8 @@ def main():
         out["train_dropout_0"] = dropout0
     if train_fp32:
         out["train_fp32"] = train_fp32
+    if train_live_attention:
+        out["train_live_attention"] = train_live_attention
     if elided:
         out["dead_attention_elided"] = elided
     if sampling:

@@ -184,6 +184,51 @@ def test_cfg_sampler_matches_oracle_and_reference_contract():
 
 # --------------------------------------------------------------------------- main_stl10.train() / inference()
 @pytest.mark.gpu
+def test_sampling_configs3_full_batch_is_sample_independent():
+    """configs[3] at its FULL size -- 11 labels x 64 samples = 704 images at 96x96, cond+uncond batched, 88 images per launch
+    as bench.py runs it -- through size-independent properties: every image of the sharded / chunked job equals the same
+    sample run in a launch of another size (GroupNorm is per sample, there is no BatchNorm: batching and sharding are
+    throughput restructurings), the unconditional label gets guidance 0, and a contiguous rank shard reproduces its slice of
+    the whole job.  A 500-step schedule walked for its first 8 steps with supplied ancestral noise (the per-step arithmetic
+    is pinned against the reference by the fixtures of test_oracle_ref_pinned.py)."""
+    from diffusion_model_amd import utils
+    from diffusion_model_amd.sampler import CFGSampler, shard_bounds
+    from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
+    model, _ = make_model(seed=3)
+    model.eval()
+    table = utils._load_clip_context_table()
+    sched = DDPM_beta_t_cosine_scheduler(500)
+    smp = CFGSampler(model, sched, table, uncond_id=10)
+    S, stop = 704, 492
+    g = torch.Generator().manual_seed(42)
+    z = torch.randn(S, 3, 96, 96, generator=g)
+    labels = torch.arange(S) % 11
+    noises = {t: torch.randn(S, 3, 96, 96, generator=g) for t in range(499, stop - 1, -1)}
+
+    def run(lo, hi, chunk):
+        outs = []
+        for c in range(lo, hi, chunk):
+            e = min(hi, c + chunk)
+            outs.append(smp.sample(z[c:e].to(dev()), labels[c:e], 6.0, 1.0, num_time_steps=500, t_stop=stop,
+                                   noises={t: n[c:e] for t, n in noises.items()}))
+        return torch.cat(outs)
+
+    full = run(0, S, 88)                                   # the bench's job: 8 launches of 88 images (UNet batch 176)
+    assert full.shape == (S, 3, 96, 96) and bool(torch.isfinite(full).all())
+    assert float(full.std()) > 0.5                         # still close to the start noise after 8 of 500 steps, not degenerate
+    for lo, hi, chunk in ((0, 16, 16), (600, 640, 20), (693, 704, 11)):
+        part = run(lo, hi, chunk)
+        assert rel_l2(part, full[lo:hi]) < 1e-2, (lo, hi, rel_l2(part, full[lo:hi]))
+    lo, hi = shard_bounds(S, 5, 8)                         # rank 5 of 8: its contiguous shard, launched as the rank would
+    assert (lo, hi) == (440, 528)
+    assert rel_l2(run(lo, hi, 88), full[lo:hi]) < 1e-2
+    # label 10 is the unconditional id: guidance 0.0 there (visualization.py:424) -> the result does not depend on the scale
+    idx = [i for i in range(22) if i % 11 == 10]
+    a = smp.sample(z[:22].to(dev()), labels[:22], 6.0, 1.0, num_time_steps=500, t_stop=stop, noises={t: n[:22] for t, n in noises.items()})
+    b = smp.sample(z[:22].to(dev()), labels[:22], 2.0, 1.0, num_time_steps=500, t_stop=stop, noises={t: n[:22] for t, n in noises.items()})
+    assert torch.equal(a[idx], b[idx]) and not torch.equal(a[:10], b[:10])
+
+
 def test_main_stl10_train_checkpoint_inference_roundtrip(tmp_path):
     """Drop-in train()/inference() (reference main_stl10.py:352-566): the epoch loop with the tail-step gate,
     the reference checkpoint dict (loadable by torch.optim.AdamW and strict state_dict loads), resume, and
