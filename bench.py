@@ -442,6 +442,21 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus))   # before anything initialises a GPU in this process
+    # stdout carries exactly ONE line, the JSON: libraries print banners there (RCCL writes its version block to stdout
+    # when a communicator is created), so file descriptor 1 points at stderr for the whole run and the result goes to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _run(a, real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _run(a, real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -778,7 +793,7 @@ def main():
         out["roofline_attention"] = attention_roofline(dev, a.batch, a.dropout)
     if not a.no_cpu_baseline and world == 1:   # the CPU leg is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out), flush=True)          # flushed before the process group is torn down
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())   # the one line of stdout; written before the process group is torn down
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -203,6 +203,21 @@ def _b(c):
     return None if c.bias is None else c.bias.detach()
 
 
+_ZEROS_RO: Dict[tuple, torch.Tensor] = {}
+
+
+def _zeros_ro(shape, dtype, device) -> torch.Tensor:
+    """A cached all-zeros tensor that callers only READ (never an output, never written in place)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(shape, dtype=dtype, device=device)   # (a first use inside a capture stays in the graph's pool)
+    key = (tuple(shape), dtype, device.index if device.type == "cuda" else -1)
+    z = _ZEROS_RO.get(key)
+    if z is None:
+        z = _ZEROS_RO[key] = torch.zeros(shape, dtype=dtype, device=device)
+        torch.cuda.current_stream(device).synchronize()   # once per shape: readers on ANY stream may follow without an event
+    return z
+
+
 def _nhwc_in(x: torch.Tensor, cpad: int = 0) -> torch.Tensor:
     return K.nchw_to_nhwc(x.detach().float().contiguous(), cpad)
 
@@ -570,8 +585,8 @@ class CrossAttention(HipModule):
                 self._add_dctx(g, None, dv)
             return add, None
         if fused:   # one key: dq and dk are exact zeros (dm_attn_bwd writes the same zeros); the rest runs as always
-            dq = torch.zeros((B, N, C), dtype=dy.dtype, device=dy.device)
-            dk = torch.zeros_like(dv)
+            dq = _zeros_ro((B, N, C), dy.dtype, dy.device)    # (read-only operands of the GEMMs below: one cached buffer
+            dk = _zeros_ro(tuple(dv.shape), dv.dtype, dv.device)  #  per shape instead of a 75 MB memset per layer and step)
         else:
             dq, dk, dv = K.attn_bwd(q, kc, vc, o, lse, d_o, self.num_heads, drop_p=p, drop_seed=seed)
         K.wgrad_side(tok, dq, g.of(self.to_q.weight), None, taps=1)
