@@ -1,4 +1,4 @@
-"""configs[2] on real kernels: the data-parallel training step with TWO ranks.  One GPU box has one GPU and RCCL refuses
+"""configs[2] on real kernels: the data-parallel training step with TWO (and FOUR) ranks.  One GPU box has one GPU and RCCL refuses
 two ranks on one device, so the ranks share cuda:0 and exchange gradients over gloo -- the Trainer, the bucket hook on
 the weight-gradient side stream (ordered behind the main AND the auxiliary stream, kernels.call_on_side), the broadcast
 of the replicas and the fused clip + AdamW + EMA are exactly the N > 1 code path; only the transport differs from RCCL:
@@ -112,8 +112,8 @@ def _worker_body(rank, world, port, q, side_wgrad):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("side_wgrad", [True, False], ids=["side_wgrad", "inline_wgrad"])
-def test_data_parallel_two_ranks_match_gradient_accumulation(side_wgrad):
+@pytest.mark.parametrize("side_wgrad,world", [(True, 2), (False, 2), (True, 4)], ids=["side_wgrad", "inline_wgrad", "four_ranks"])
+def test_data_parallel_ranks_match_gradient_accumulation(side_wgrad, world):
     import queue as _queue
     import socket
     import torch.multiprocessing as mp
@@ -122,14 +122,14 @@ def test_data_parallel_two_ranks_match_gradient_accumulation(side_wgrad):
     with socket.socket() as sk:          # a port that is free right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, side_wgrad)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, side_wgrad)) for r in range(world)]
     for p in procs:
         p.start()
     try:
         res = [q.get(timeout=90) for _ in procs]
     except _queue.Empty:
         codes = [p.exitcode for p in procs]
-        for r in range(2):
+        for r in range(world):
             try:
                 with open(os.path.join(tempfile.gettempdir(), "dm_dp_rank%d_%d.trace" % (r, port))) as f:
                     codes.append("rank %d: %s" % (r, f.read()[-2500:]))
@@ -146,23 +146,25 @@ def test_data_parallel_two_ranks_match_gradient_accumulation(side_wgrad):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    r0, r1 = [{k: (torch.from_numpy(v) if hasattr(v, 'dtype') else v) for k, v in r.items()} for r in res]
-    # replicas: rank 1 started from another init and must hold rank 0's parameters after Trainer.__init__
-    assert torch.equal(r0["p0"], r1["p0"])
-    # the ranks reduce the same buckets and run the same fused optimizer: identical gradients and parameters, bit for bit
-    for k in ("g0", "g1", "p1", "p2"):
-        assert torch.equal(r0[k], r1[k]), k
+    rs = [{k: (torch.from_numpy(v) if hasattr(v, 'dtype') else v) for k, v in r.items()} for r in res]
+    r0 = rs[0]
+    for r1 in rs[1:]:
+        # replicas: the other ranks started from other inits and must hold rank 0's parameters after Trainer.__init__
+        assert torch.equal(r0["p0"], r1["p0"])
+        # the ranks reduce the same buckets and run the same fused optimizer: identical gradients and parameters, bit for bit
+        for k in ("g0", "g1", "p1", "p2"):
+            assert torch.equal(r0[k], r1[k]), k
     # ... and the reduced gradient is the gradient-accumulation gradient of one process over both ranks' batches
     from diffusion_model_amd.trainer import Trainer
     from diffusion_model_amd.utils import DDPM_beta_t_cosine_scheduler
     from diffusion_model_amd import kernels as K
     model = _make(10)
-    tr = Trainer(model, DDPM_beta_t_cosine_scheduler(500), lr=1e-3, clip=1.0, accum=2, total_steps=100, low_t_weight=0.01)
+    tr = Trainer(model, DDPM_beta_t_cosine_scheduler(500), lr=1e-3, clip=1.0, accum=world, total_steps=100, low_t_weight=0.01)
     assert torch.equal(tr.fp.flat.detach().cpu(), r0["p0"])
     tr.defer_optimizer = True
     dev = torch.device("cuda:0")
     for step in range(2):
-        for rank in range(2):
+        for rank in range(world):
             tr.micro_step(*[v.to(dev) for v in _batch(100 + 10 * step + rank)])
         K.join_side(dev)
         torch.cuda.synchronize()
