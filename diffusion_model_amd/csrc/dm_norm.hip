@@ -587,6 +587,219 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
   }
 }
 
+// ONE-PASS backward for the slabs the half-CU forward takes (16-channel groups and wider, up to 9 pieces per thread):
+// a 512-thread workgroup at <= 128 VGPRs owns one (sample, group) slab.  The dy slab rides in registers, the x slab in
+// LDS (each thread writes and re-reads its own 16-byte pieces: conflict-free by construction), so x and dy are read
+// ONCE: 6 B/element (8 with the residual add) instead of the two-pass 10 (12).  Phase 1 forms the per-channel sums
+// {sum dz, sum dz*xhat}; the workgroup holds every pixel of its channels, so the sums are complete: they go to the
+// workspace row of the sample (the dgamma / dbeta reduction reads one row per sample) and, weighted by gamma, give the
+// group means the apply phase needs -- no (split, group) partial table.  All merges are a fixed shuffle tree plus ordered
+// LDS sums: bit-reproducible like the two-pass kernels.  Out-of-range pieces (pixel >= HW) read zeros through the buffer
+// descriptor (dz = 0 adds nothing to the sums) and their stores are dropped.
+constexpr int OPB_THREADS = 512;
+// MINW = waves per SIMD the register budget is cut for: 4 (<= 128 VGPRs, two workgroups per CU) up to 9 pieces per thread;
+// the 18-piece slabs (256ch@48x48: 147 KB of LDS, one workgroup per CU anyway) take MINW = 2.
+__device__ __forceinline__ void opb_wait_vmcnt(int n) {   // s_waitcnt vmcnt(n) for a compile-time-foldable n
+#define DM_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    DM_VMC(0) DM_VMC(2) DM_VMC(4) DM_VMC(6) DM_VMC(8) DM_VMC(10) DM_VMC(12) DM_VMC(14) DM_VMC(16) DM_VMC(18) DM_VMC(20)
+    DM_VMC(22) DM_VMC(24) DM_VMC(26) DM_VMC(28) DM_VMC(30) DM_VMC(32) DM_VMC(34)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#undef DM_VMC
+}
+template <int MAXP, int MINW, bool ACT>
+__global__ __launch_bounds__(OPB_THREADS, MINW) void gn_onepass2_bwd_kernel(
+    const bf16* __restrict__ x, long ldx, const float* __restrict__ chan_add, const bf16* __restrict__ dy, long lddy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
+    const bf16* __restrict__ add_in, long ldadd, bf16* __restrict__ dx, long lddx, float* __restrict__ ws,
+    float* __restrict__ colpart, int B, int HW, int C, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale,
+    const uint32_t* __restrict__ seed_ctr) {
+  constexpr int T = OPB_THREADS, NW = T / 64, CH = 8;   // CH: channels per 16-byte piece
+  typedef u32x4 U;
+  typedef bf16x8 Hv;
+  extern __shared__ __attribute__((aligned(16))) char op_smem[];
+  U* sx = reinterpret_cast<U*>(op_smem);                                             // [MAXP][T] x pieces
+  float* red = reinterpret_cast<float*>(op_smem + (size_t)MAXP * T * sizeof(U));     // [NW][cpg][2] wave partials
+  __shared__ float s_g[2 * 128], s_m[2];
+  if (drop_thresh) drop_seed = dm_eff_seed(drop_seed, seed_ctr);
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3, g = jj & 7, b = (jj >> 3) * 8 + xcd;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cpg = C >> 3, ppp = cpg / CH;
+  const int sub = tid % ppp, c0 = g * cpg + sub * CH;
+  const int pix0 = tid / ppp, pstep = T / ppp;
+  const float mean = stats[((long)b * 8 + g) * 2], rstd = stats[((long)b * 8 + g) * 2 + 1];
+  float ga[CH], be[CH], add[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+    add[j] = chan_add ? chan_add[(long)b * C + c0 + j] : 0.f;
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * HW * ldx), 0, (int)((((long)HW - 1) * ldx + C) * 2), 0x00020000);
+  const auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (long)b * HW * lddy), 0, (int)((((long)HW - 1) * lddy + C) * 2), 0x00020000);
+  const auto ro = __builtin_amdgcn_make_buffer_rsrc((void*)(dx + (long)b * HW * lddx), 0, (int)((((long)HW - 1) * lddx + C) * 2), 0x00020000);
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(add_in ? add_in + (long)b * HW * ldadd : x), 0,
+                                                    add_in ? (int)((((long)HW - 1) * ldadd + C) * 2) : 0, 0x00020000);
+  const int vx = (int)((pix0 * ldx + c0) * 2), vd = (int)((pix0 * lddy + c0) * 2), vo = (int)((pix0 * lddx + c0) * 2),
+            va = (int)((pix0 * ldadd + c0) * 2);
+  const int sxs = (int)(pstep * ldx * 2), sds = (int)(pstep * lddy * 2), sos = (int)(pstep * lddx * 2), sas = (int)(pstep * ldadd * 2);
+  // the two per-element quantities both phases need (same expressions as the two-pass kernels)
+  auto dz_xh = [&](float xv, float dv, int j, float& xh) {
+    xh = (xv + add[j] - mean) * rstd;
+    float dz = dv;
+    if constexpr (ACT) {
+      const float z = xh * ga[j] + be[j];
+      const float sg = dm_sigmoid(z);
+      dz *= sg * (1.f + z * (1.f - sg));
+    }
+    return dz;
+  };
+  // ---- phase 1: dy slab -> registers; x slab -> LDS by direct-to-LDS buffer loads (no registers: the whole slab is in
+  // flight at once; a wave's 64 lanes land contiguously at its wave-uniform base, which is the [piece][thread] image);
+  // then the channel sums.  Each lane reads back only what its own wave's loads wrote: no barrier, a vmcnt wait suffices --
+  // but the compiler does not order a ds_read behind the LDS-DMA that fills it, so the waits are explicit: the loads are
+  // issued strictly as (x0, dy0, x1, dy1, ...) and piece k waits for vmcnt(2 * (MAXP - 1 - k)), i.e. for its own two loads
+  // only, while the later pieces are still in flight (load and arithmetic overlap inside every wave).
+  U dv[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + k * T + wave * 64), 16, vx, k * sxs, 0, 0);
+    dv[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vd, k * sds, 0));
+    __builtin_amdgcn_sched_barrier(0);   // keep the issue order the counted waits below assume
+  }
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  constexpr int XB = 3;   // (phase 2: residual pieces in flight beside the dy slab)
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    opb_wait_vmcnt(2 * (MAXP - 1 - k));
+    __builtin_amdgcn_sched_barrier(0);
+    if (pix0 + k * pstep < HW) {   // (a piece past the last pixel: nothing was written to its LDS slot)
+      const Hv h = __builtin_bit_cast(Hv, sx[k * T + tid]), d = __builtin_bit_cast(Hv, dv[k]);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        float xh;
+        const float dz = dz_xh((float)h[j], (float)d[j], j, xh);
+        s1[j] += dz; s2[j] += dz * xh;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one piece at a time: interleaving the unrolled pieces spills
+  }
+  // fixed shuffle tree over the lanes that hold the same CH channels, then the waves in order through LDS
+  auto channel_sums = [&](float (&a)[CH], float (&c)[CH], bool two) {
+    for (int o = ppp; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        a[j] += __shfl_xor(a[j], o, 64);
+        if (two) c[j] += __shfl_xor(c[j], o, 64);
+      }
+    }
+    if (lane < ppp) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        red[((wave * cpg) + lane * CH + j) * 2] = a[j];
+        if (two) red[((wave * cpg) + lane * CH + j) * 2 + 1] = c[j];
+      }
+    }
+  };
+  channel_sums(s1, s2, true);
+  __syncthreads();
+  if (tid < cpg) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int w = 0; w < NW; ++w) { a1 += red[(w * cpg + tid) * 2]; a2 += red[(w * cpg + tid) * 2 + 1]; }
+    float* o = ws + ((long)b * C + g * cpg + tid) * 2;   // the sample's row of {sum dz, sum dz*xhat} per channel
+    o[0] = a1; o[1] = a2;
+    const float gm = gamma[g * cpg + tid];
+    s_g[tid * 2] = gm * a1; s_g[tid * 2 + 1] = gm * a2;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    float m = 0.f;
+    for (int c = 0; c < cpg; ++c) m += s_g[c * 2 + tid];
+    s_m[tid] = m / ((float)cpg * (float)HW);
+  }
+  __syncthreads();
+  const float m1 = s_m[0], m2 = s_m[1];
+  // (the dy registers are made opaque here: otherwise the compiler keeps phase 1's bf16 -> fp32 conversions of the whole slab
+  // alive for phase 2 -- twice the registers -- instead of converting again)
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k)
+#pragma unroll
+    for (int q = 0; q < CH / 2; ++q) asm volatile("" : "+v"(dv[k][q]));
+  // ---- phase 2: dx = rstd * (dz*gamma - m1 - xhat*m2), dropout mask, residual add, column sums of the written dx
+  float csum[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) csum[j] = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < MAXP; k0 += XB) {
+    U av[XB];
+    if (add_in) {
+#pragma unroll
+      for (int i = 0; i < XB; ++i)
+        if (k0 + i < MAXP) av[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, va, (k0 + i) * sas, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int k = k0 + i;
+      if (k < MAXP) {
+        const int pix = pix0 + k * pstep;
+        if (pix < HW) {
+          const Hv h = __builtin_bit_cast(Hv, sx[k * T + tid]), d = __builtin_bit_cast(Hv, dv[k]);
+          Hv a8 = {};
+          if (add_in) a8 = __builtin_bit_cast(Hv, av[i]);
+          uint32_t db[CH / 2];
+#pragma unroll
+          for (int j = 0; j < CH / 2; ++j) db[j] = 0u;
+          if (drop_thresh) {
+            const uint32_t rs = dm_drop_row(drop_seed, (uint32_t)((long)b * HW + pix));
+#pragma unroll
+            for (int j = 0; j < CH / 2; ++j) db[j] = dm_drop_bits(rs, ((uint32_t)c0 >> 1) + j);
+          }
+          Hv o;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            float xh;
+            const float dz = dz_xh((float)h[j], (float)d[j], j, xh);
+            float r = rstd * (dz * ga[j] - m1 - xh * m2);
+            if (drop_thresh) r = dm_keep16(db[j >> 1], (uint32_t)j, drop_thresh) ? r * drop_scale : 0.f;
+            if (add_in) r += (float)a8[j];
+            o[j] = (bf16)r;
+            csum[j] += (float)o[j];
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(ro, 0, 0, 0)), o),
+                                                 ro, vo, k * sos, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (colpart) {
+    __syncthreads();   // (red is re-used)
+    channel_sums(csum, csum, false);
+    __syncthreads();
+    if (tid < cpg) {
+      float a = 0.f;
+      for (int w = 0; w < NW; ++w) a += red[(w * cpg + tid) * 2];
+      colpart[(long)b * C + g * cpg + tid] = a;
+    }
+  }
+}
+bool gn_onepass_bwd_ok(int HW, int C, int G) {
+  // DM_GN_ONEPASS_BWD (developer switch, read per call: tests switch it at run time): the largest slab, in 16-byte pieces per
+  // thread, the one-pass backward takes; 0 = two passes everywhere.  Default 9: measured alone (tools/hbmbench.py, B=64, whole
+  // backward incl. the parameter-gradient kernels, two passes -> one): 128ch@48x48 54.4 -> 47.0 us, 256ch@24x24 39.0 -> 26.5;
+  // the 18-piece slabs (256ch@48x48: one workgroup per CU) 81.8 -> 85.7 and stay on the two passes.  The kernel is bound by
+  // its arithmetic (the SiLU derivative is evaluated in both phases, as in the two passes) plus the un-overlapped load
+  // phase, not by HBM; inside the multi-stream training step the change is neutral (14.79 vs 14.79 ms, tools/gnb_ab.sh).
+  const char* e = getenv("DM_GN_ONEPASS_BWD");
+  const int maxp = e ? atoi(e) : 9;
+  if (maxp <= 0 || gn_onepass_mode() != 2 || !gn_onepass_ok(HW, C, G)) return false;
+  const int cpg = C / G;
+  return cpg <= 128 && (long)HW * (cpg / 8) <= (long)OPB_THREADS * (maxp < 18 ? maxp : 18);
+}
+
 // dgamma[c] += sum over (sample, split) rows of ws[row][c][1], dbeta[c] += ... [0], in two ORDERED stages (no atomics:
 // bit-reproducible).  Stage 1, grid (ceil(2C/64), RB): a block owns 64 consecutive floats of the 2C-float rows and R/RB
 // rows (4 row lanes, loads unrolled, ordered LDS combine) and writes its share to wsp[blockIdx.y][2C].  Stage 2
@@ -718,11 +931,50 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
   float* colpart = wsg + (long)B * ns * G * 2;   // per-(sample, chunk) column sums of dx
   float* wsp = colpart + (long)B * ns * C;       // parameter-gradient shares of stage 1
   hipStream_t st = (hipStream_t)stream;
+  const uint32_t thresh = dm_thresh16(drop_p);
+  const float scale = dm_inv_keep(drop_p);
+  if (gn_onepass_bwd_ok(HW, C, G)) {
+    // one (sample, group) slab per workgroup: one workspace row and one column-sum row per sample (ns = 1 below)
+    const long pieces = ((long)HW * (C / G / 8) + OPB_THREADS - 1) / OPB_THREADS;
+    float* colpart1 = ws + (long)B * C * 2;
+    float* wsp1 = colpart1 + (long)B * C;
+    const dim3 grid(((B + 7) / 8) * 64), blk(OPB_THREADS);
+    int rc = DM_OK;
+#define DM_OPB(P, MW)                                                                                                           \
+  do {                                                                                                                      \
+    constexpr int LDS = P * OPB_THREADS * 16 + (OPB_THREADS / 64) * 128 * 2 * 4;                                            \
+    auto k = act_silu ? gn_onepass2_bwd_kernel<P, MW, true> : gn_onepass2_bwd_kernel<P, MW, false>;                         \
+    static unsigned long long attr_devs0 = 0ull, attr_devs1 = 0ull;                                                         \
+    unsigned long long& attr_devs = act_silu ? attr_devs1 : attr_devs0;                                                     \
+    if (dm_first_on_device(attr_devs) &&                                                                                    \
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {               \
+      rc = DM_ERR_LAUNCH;                                                                                                   \
+      break;                                                                                                                \
+    }                                                                                                                       \
+    const int lds = P * OPB_THREADS * 16 + (OPB_THREADS / 64) * (C / G) * 2 * 4;   /* <= 80 KB: two workgroups per CU */     \
+    hipLaunchKernelGGL(k, grid, blk, lds, st, (const bf16*)x, ldx, chan_add, (const bf16*)dy, lddy, gamma, beta, stats,     \
+                       (const bf16*)add_in, ldadd, (bf16*)dx, lddx, ws, dx_colsum ? colpart1 : nullptr, B, HW, C,           \
+                       dm_seed32(drop_seed), thresh, scale, dm_dropout_counter());                                          \
+  } while (0)
+    if (pieces <= 5) { dm_set_variant("gn_onepass2_bwd<5>"); DM_OPB(5, 4); }
+    else if (pieces <= 9) { dm_set_variant("gn_onepass2_bwd<9>"); DM_OPB(9, 4); }
+    else { dm_set_variant("gn_onepass2_bwd<18>"); DM_OPB(18, 2); }
+#undef DM_OPB
+    if (rc != DM_OK) return rc;
+    DM_LAUNCH_CHECK();
+    const int RB1 = B < 16 ? B : 16;
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, RB1), dim3(256), 0, st, ws, wsp1, B, C);
+    DM_LAUNCH_CHECK();
+    const int nfin1 = 2 * C + (dx_colsum ? B * C : 0);
+    hipLaunchKernelGGL(gn_param_final_kernel, dim3((nfin1 + 255) / 256), dim3(256), 0, st, wsp1, RB1, dgamma, dbeta, colpart1,
+                       dx_colsum, B, C, 1);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+  }
+  dm_set_variant("gn_bwd_reduce+gn_bwd_apply");
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, ws, wsg, HW, C, G, ns, act_silu);
   DM_LAUNCH_CHECK();
-  const uint32_t thresh = dm_thresh16(drop_p);
-  const float scale = dm_inv_keep(drop_p);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ns, B), dim3(256), 0, st, (const bf16*)x, ldx, chan_add,
                      (const bf16*)dy, lddy, gamma, beta, stats, wsg, ns, (const bf16*)add_in, ldadd, (bf16*)dx,
                      lddx, HW, C, G, ns, act_silu, dm_seed32(drop_seed), thresh, scale, dx_colsum ? colpart : nullptr,

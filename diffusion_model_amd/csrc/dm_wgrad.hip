@@ -47,13 +47,21 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a0, const char* a1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false>
+// CIW (1x1 / linear gradients only): 64-channel ci sub-tiles per workgroup.  With CIW = 2 a workgroup owns 64 co x 128 ci:
+// the dy fragments of a k-step feed 8 MFMAs instead of 4 (the 1x1 kernel is LDS-read bound: 10 transposed reads per 4
+// MFMAs), dy is re-read from memory by half as many ci tiles, and half as many slabs are written.  The second 64 channels
+// of a pixel live in a second LDS plane with the same 160-byte pixel stride (a 320-byte stride would be 2-way conflicted).
+// The accumulator index plays the role the tap index plays for 3x3 weights.
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false, int CIW = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  static_assert(CIW == 1 || (MODE == WM_GEMM && TAPS == 1 && !NORM), "ci sub-tiles are a 1x1 / linear option");
+  constexpr int NA = TAPS * CIW;   // accumulator blocks (taps, or ci sub-tiles)
   constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
   constexpr int PW = (MODE == WM_GEMM) ? TW : ((S == 1) ? TW + 2 : 2 * TW + 1);
   constexpr int NPIX = TH * TW;
   constexpr int KSTEPS = NPIX / 32;
-  constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
+  constexpr int X_PLANE = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
+  constexpr int X_BYTES = X_PLANE * CIW;
   static_assert(NPIX % 32 == 0 && TW % 8 == 0, "k-step = 32 pixels, 8 consecutive pixels per row segment");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,10 +72,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int split = blockIdx.x, cot = blockIdx.y, cit = blockIdx.z;
   const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
 
-  f32x4 acc[TAPS][4];
+  f32x4 acc[NA][4];
   f32x4 accb[4];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < NA; ++t)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -90,7 +98,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // Staging is software-pipelined over the tiles this workgroup sweeps: the x patch and dy tile of
   // the NEXT tile are fetched into registers (all loads in flight together) while the MFMAs of the
   // current tile run, and written to LDS after the barrier that retires the current images.
-  constexpr int X_PIECES = PH * PW * 8;
+  constexpr int PPP = 8 * CIW;           // 16-byte pieces per pixel of the x image
+  constexpr int X_PIECES = PH * PW * PPP;
   constexpr int NPX = (X_PIECES + 255) / 256;
   constexpr int NPD = (NPIX * 8 + 255) / 256;
   static_assert((NPIX * 8) % 256 == 0, "dy tile pieces must divide evenly over the workgroup");
@@ -134,12 +143,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
         const int idx = tid + i * 256;
-        const int piece = idx & 7;
-        const int pix = idx >> 3;
+        const int piece = idx % PPP;
+        const int pix = idx / PPP;
         const int pr = pix / PW, pc = pix % PW;
         bool valid = idx < X_PIECES;
         int off;
-        const int ch = cit * 64 + piece * 8;
+        const int ch = cit * 64 * CIW + piece * 8;
         if constexpr (MODE == WM_GEMM) {
           valid = valid && (m0 + pix < p.M) && (ch < p.Cin);
           off = (pix * (int)p.ldx + ch) * 2;
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       const int idx = tid + i * 256;
-      const int piece = idx & 7;
-      const int pix = idx >> 3;
+      const int piece = idx % PPP;
+      const int pix = idx / PPP;
       const int pr = pix / PW, pc = pix % PW;
       u32x4 v = px[i];
       if (p.act_silu_in) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         v = __builtin_bit_cast(u32x4, h);
       }
       if (X_PIECES % 256 == 0 || idx < X_PIECES)
-        *reinterpret_cast<u32x4*>(sX + (pr * XPITCH + pc) * XSTRIDE + piece * 16) = v;
+        *reinterpret_cast<u32x4*>(sX + (piece >> 3) * X_PLANE + (pr * XPITCH + pc) * XSTRIDE + (piece & 7) * 16) = v;
     }
     if (do_d)
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
   // The prefetch registers stay live across the MFMA phase; tile shapes whose images need more than
   // 40 of them would spill next to the 160 accumulators, so those fetch (batched) right before the write.
-  constexpr bool PREFETCH = (NPX + NPD) <= 10;
+  constexpr bool PREFETCH = (NPX + NPD) <= (NA >= 9 ? 10 : 16);   // (few accumulators: room for a deeper prefetch)
   u32x4 px[NPX], pd[NPD];
   if (PREFETCH && split < p.ntiles) load_tile(split, px, pd, true, true);
   for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
@@ -275,14 +284,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       // every tap paid the LDS latency between its read and its first MFMA)
       auto xfrag = [&](int tap) {
         const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
-        const int tapoff = (kh * XPITCH + kw) * XSTRIDE;
+        const int tapoff = (TAPS == 9) ? (kh * XPITCH + kw) * XSTRIDE : tap * X_PLANE;   // 1x1: ci sub-tile = LDS plane
         return tr_pair(sX + xo[0] + tapoff, sX + xo[1] + tapoff);
       };
       bf16x8 bv = xfrag(0);
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
+      for (int tap = 0; tap < NA; ++tap) {
         bf16x8 bn = bv;
-        if (tap + 1 < TAPS) bn = xfrag(tap + 1);
+        if (tap + 1 < NA) bn = xfrag(tap + 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[tap][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bv, acc[tap][t], 0, 0, 0);
         bv = bn;
@@ -291,17 +300,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   // ---- write the slab (fragment order): [tap][cosub][wave][lane][4] then bias [cosub][lane][4]
-  const long slab_floats = (long)TAPS * 4 * 4 * 256 + SLAB_BIAS;
+  const long slab_floats = (long)NA * 4 * 4 * 256 + SLAB_BIAS;
   float* slab = p.slab + (((long)split * gridDim.y + cot) * gridDim.z + cit) * slab_floats;
 #pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap)
+  for (int tap = 0; tap < NA; ++tap)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       *reinterpret_cast<f32x4*>(slab + (((tap * 4 + t) * 4 + wave) * 64 + lane) * 4) = acc[tap][t];
   if (do_bias) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      *reinterpret_cast<f32x4*>(slab + (long)TAPS * 4 * 4 * 256 + (t * 64 + lane) * 4) = accb[t];
+      *reinterpret_cast<f32x4*>(slab + (long)NA * 4 * 4 * 256 + (t * 64 + lane) * 4) = accb[t];
   }
 }
 
@@ -312,10 +321,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // in lane order before the single read-modify-write of dw.  L follows the split count (64+ slabs: L = 16; the few
 // slabs of a large gradient: L = 4), so every shape has enough loads in flight.  The blocks behind
 // the accumulator range do the same for the bias column (64 channels x 16 slab lanes).
+// ciw > 1 (1x1 gradients with ci sub-tiles): the slab's block index is the ci sub-tile, not a tap (`taps` = ciw there).
 template <int L>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                             float* __restrict__ dbias, int nsplit, int ncot, int ncit,
-                                                            int taps, int Kreal, int Nreal, int nblk_main) {
+                                                            int taps, int Kreal, int Nreal, int nblk_main, int ciw) {
   constexpr int Q = 1024 / L;
   __shared__ f32x4 red[1024];
   const long slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
@@ -350,11 +360,14 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
       const int cot = (int)(tile / ncit), cit = (int)(tile % ncit);
       const int ln = (e >> 2) & 63, wv = (e >> 8) & 3, t = (e >> 10) & 3, tap = e >> 12;
       const int co = cot * 64 + t * 16 + (ln >> 4) * 4;
-      const int ci = cit * 64 + wv * 16 + (ln & 15);
+      const int ci = (ciw > 1 ? (cit * ciw + tap) * 64 : cit * 64) + wv * 16 + (ln & 15);
       if (ci < Kreal) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < Nreal) dw[((long)(co + r) * Kreal + ci) * taps + tap] += sum[r];
+          if (co + r < Nreal) {
+            if (ciw > 1) dw[(long)(co + r) * Kreal + ci] += sum[r];
+            else dw[((long)(co + r) * Kreal + ci) * taps + tap] += sum[r];
+          }
       }
     }
     return;
@@ -381,12 +394,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-struct Plan { int th, tw, ntiles, nsplit, ncot, ncit; long slab_floats; };
+struct Plan { int th, tw, ntiles, nsplit, ncot, ncit, ciw; long slab_floats; };
 
 Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
   Plan pl{};
-  pl.ncot = (Cout + 63) / 64; pl.ncit = (Cin + 63) / 64;
-  pl.slab_floats = (long)taps * 4 * 4 * 256 + SLAB_BIAS;
+  // 1x1 / linear gradients over 256 input channels and more: two ci sub-tiles per workgroup (wgrad_kernel's CIW).  Measured
+  // (tools/convbench.py, B=64, same box, CIW 1 -> 2): 256->128 M=147k 33.5 -> 29.8 us, 256->256 M=37k 21.1 -> 20.5; at 128 input
+  // channels the single ci tile leaves twice the splits and the doubled slab loses: 128->64 M=590k 41.2 -> 46.7, 128->128 22.5 -> 23.5.
+  static const int ciw_min = [] { const char* e = getenv("DM_WGRAD_CIW_MINCIN"); return e ? atoi(e) : 256; }();   // developer switch
+  pl.ciw = (taps == 1 && Cin % 128 == 0 && Cin >= ciw_min) ? 2 : 1;
+  pl.ncot = (Cout + 63) / 64; pl.ncit = (Cin + 64 * pl.ciw - 1) / (64 * pl.ciw);
+  pl.slab_floats = (long)taps * pl.ciw * 4 * 4 * 256 + SLAB_BIAS;
   int Ho = H, Wo = W;
   if (mode == 1) { Ho = H / 2; Wo = W / 2; }
   if (mode == 2) { Ho = 2 * H; Wo = 2 * W; }
@@ -412,19 +430,20 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout, int taps, int mode) {
   return pl;
 }
 
-template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false>
+template <int TH, int TW, int S, int XPITCH, int XSTRIDE, int MODE, int TAPS, bool NORM = false, int CIW = 1>
 int launch_wgrad(const WgradParams& p, const Plan& pl, hipStream_t st) {
   constexpr int PH = (MODE == WM_GEMM) ? TH : ((S == 1) ? TH + 2 : 2 * TH + 1);
-  constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16;
+  constexpr int X_BYTES = ((PH * XPITCH * XSTRIDE + 15) / 16) * 16 * CIW;
   constexpr int LDS = X_BYTES + TH * TW * DYS;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
-  auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS, NORM>;
+  auto k = wgrad_kernel<TH, TW, S, XPITCH, XSTRIDE, MODE, TAPS, NORM, CIW>;
   static unsigned long long attr_devs = 0ull;
   if (dm_first_on_device(attr_devs)) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return DM_ERR_LAUNCH;
   }
-  static const DmVariantName vn(NORM ? "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d,NORM>" : "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>",
+  static const DmVariantName vn(NORM ? "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d,NORM>"
+                                     : (CIW > 1 ? "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d,CIW=2>" : "wgrad<TH=%d,TW=%d,S=%d,MODE=%d,TAPS=%d>"),
                                 TH, TW, S, MODE, TAPS);
   dm_set_variant(vn.s);
   hipLaunchKernelGGL(k, dim3(pl.nsplit, pl.ncot, pl.ncit), dim3(256), LDS, st, p);
@@ -466,7 +485,8 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
     else if (pl.tw == 24) rc = launch_wgrad<8, 24, 1, 26, 160, WM_S1, 9, true>(p, pl, st);
     else rc = launch_wgrad<8, 8, 1, 10, 160, WM_S1, 9, true>(p, pl, st);
   } else
-  if (a->taps == 1) rc = launch_wgrad<8, 16, 1, 16, 160, WM_GEMM, 1>(p, pl, st);
+  if (a->taps == 1) rc = pl.ciw == 2 ? launch_wgrad<8, 16, 1, 16, 160, WM_GEMM, 1, false, 2>(p, pl, st)
+                                     : launch_wgrad<8, 16, 1, 16, 160, WM_GEMM, 1>(p, pl, st);
   else if (a->mode == 1) rc = launch_wgrad<8, 8, 2, 17, 144, WM_S2, 9>(p, pl, st);
   else if (pl.tw == 16) rc = (a->mode == 0) ? launch_wgrad<8, 16, 1, 18, 160, WM_S1, 9>(p, pl, st)
                                             : launch_wgrad<8, 16, 1, 18, 160, WM_UP, 9>(p, pl, st);
@@ -477,7 +497,8 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   if (rc != DM_OK) return rc;
   const int Nreal = a->n_valid > 0 ? a->n_valid : a->Cout;
   const int Kreal = a->k_valid > 0 ? a->k_valid : a->Cin;
-  const long total4 = (long)pl.ncot * pl.ncit * a->taps * 1024;  // accumulator quads
+  const int slab_taps = a->taps * pl.ciw;
+  const long total4 = (long)pl.ncot * pl.ncit * slab_taps * 1024;  // accumulator quads
   // slab lanes per block (measured, tools/convbench.py: 64 lanes were no faster than 16 on the 512-slab shapes)
   const int L = pl.nsplit >= 64 ? 16 : 4;
   const int Q = 1024 / L;
@@ -485,7 +506,7 @@ extern "C" int dm_wgrad(const dm_wgrad_args* a, dm_stream_t stream) {
   const int nblk = nblk_main + (a->dbias ? pl.ncot : 0);
 #define DM_RED(LL)                                                                                               \
   hipLaunchKernelGGL(wgrad_reduce_kernel<LL>, dim3(nblk), dim3(1024), 0, st, (const float*)a->workspace, a->dw, \
-                     a->dbias, pl.nsplit, pl.ncot, pl.ncit, a->taps, Kreal, Nreal, nblk_main)
+                     a->dbias, pl.nsplit, pl.ncot, pl.ncit, slab_taps, Kreal, Nreal, nblk_main, pl.ciw)
   if (L == 16) DM_RED(16); else DM_RED(4);
 #undef DM_RED
   DM_LAUNCH_CHECK();

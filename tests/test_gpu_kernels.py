@@ -164,7 +164,8 @@ def test_wgrad_conv(K, B, H, W, Cin, Cout, mode):
     assert_close(db - 1.0, gb, 5e-3, "bias grad")
 
 
-@pytest.mark.parametrize("M,Kd,N", [(64, 256, 256), (1000, 64, 128), (4608, 128, 384), (300, 32, 64), (2, 512, 64)])
+@pytest.mark.parametrize("M,Kd,N", [(64, 256, 256), (1000, 64, 128), (4608, 128, 384), (300, 32, 64), (2, 512, 64),
+                                    (1000, 384, 128), (777, 192, 64)])   # 128-wide ci tiles (three of them); 192: 64-wide path
 def test_wgrad_linear(K, M, Kd, N):
     x = q16(rnd(M, Kd, seed=1))
     dy = q16(rnd(M, N, seed=2))
@@ -518,6 +519,71 @@ def test_gn_onepass_forward_full_size_and_dispatch(K, monkeypatch):
         assert K.last_variant() == variant
         r = F.group_norm(xs, 8, gs, bs, 1e-5)
         assert_close(nchw(ys), F.silu(r) if Hs != 5 else r, BF, variant)
+
+
+@pytest.mark.parametrize("shape,variant", [((3, 24, 24, 256), "gn_onepass2_bwd<5>"), ((2, 48, 48, 128), "gn_onepass2_bwd<9>"),
+                                           ((9, 48, 48, 256), "gn_onepass2_bwd<18>"), ((2, 40, 33, 256), "gn_onepass2_bwd<18>"),
+                                           ((2, 5, 7, 128), "gn_onepass2_bwd<5>"), ((2, 8, 8, 1024), "gn_onepass2_bwd<5>"),
+                                           ((2, 47, 48, 128), "gn_onepass2_bwd<9>")])
+@pytest.mark.parametrize("full", [False, True])
+def test_gn_onepass_backward(K, monkeypatch, shape, variant, full):
+    """GroupNorm(+SiLU) backward in ONE pass (gn_onepass2_bwd_kernel: the x slab of a (sample, group) in LDS, the dy slab in
+    registers) against the two-pass kernels and against torch autograd: every instantiation, ragged pixel counts, more than
+    eight samples; `full` adds what the ResBlock backward passes -- channel add, residual add_in, dropout mask, fused
+    column sums, strided x / dy / dx views of wider buffers -- and drops the activation on one shape."""
+    B, H, W, C = shape
+    act = not (full and H == 5)
+    xw = q16(rnd(B, H, W, 2 * C, seed=1) * 1.2 + 0.2).to(torch.bfloat16)
+    dyw = q16(rnd(B, H, W, C + 64, seed=2)).to(torch.bfloat16)
+    x, dy = (xw[..., C:], dyw[..., :C]) if full else (xw[..., C:].contiguous(), dyw[..., :C].contiguous())
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    ca = rnd(B, C, seed=5) if full else None
+    add_in = q16(rnd(B, H, W, C, seed=6)).to(torch.bfloat16) if full else None
+    p, seed = (0.1, 1234) if full else (0.0, 0)
+    _, stats = K.gn_silu_fwd(x, gamma, beta, 8, chan_add=ca, act=act)
+
+    def run(env):
+        if env is None:
+            monkeypatch.delenv("DM_GN_ONEPASS_BWD", raising=False)
+        else:
+            monkeypatch.setenv("DM_GN_ONEPASS_BWD", env)
+        dg, db = torch.full((C,), 0.25, device=dev()), torch.full((C,), -0.5, device=dev())
+        cs = torch.full((B, C), 0.5, device=dev()) if full else None
+        buf = torch.full((B, H, W, 2 * C), 3.0, dtype=torch.bfloat16, device=dev())
+        out = buf[..., :C] if full else None
+        dx = K.gn_silu_bwd(x, dy, gamma, beta, stats, 8, dg, db, chan_add=ca, add_in=add_in, act=act, drop_p=p, drop_seed=seed,
+                           out=out, colsum_out=cs)
+        v = K.last_variant()
+        if full:
+            assert float((buf[..., C:].float() - 3.0).abs().max()) == 0.0
+        return dx.float().clone(), dg, db, cs, v
+
+    dx2, dg2, db2, cs2, v2 = run("0")
+    assert v2 == "gn_bwd_reduce+gn_bwd_apply"
+    big = variant.endswith("<18>")       # the 18-piece slabs are opt-in (slower than the two passes when run alone)
+    dx1, dg1, db1, cs1, v1 = run("18" if big else None)
+    assert v1 == variant
+    if big:
+        assert run(None)[4] == "gn_bwd_reduce+gn_bwd_apply"
+    assert_close(dx1, dx2, BF, "one-pass vs two-pass dx")
+    assert float((dx1 != dx2).float().mean()) < 0.02     # same expressions; only the group means are summed in another order
+    assert_close(dg1, dg2, 1e-4, "dgamma", atol_frac=1e-5)
+    assert_close(db1, db2, 1e-4, "dbeta", atol_frac=1e-5)
+    if full:
+        assert_close(cs1, cs2, 1e-4, "column sums", atol_frac=1e-4)
+        assert torch.allclose(cs1, dx1.sum(dim=(1, 2)) + 0.5, rtol=1e-4, atol=2e-3)
+        assert float(((dx1 - add_in.float()) == 0).float().mean()) > 0.05     # the dropout mask is applied
+    else:
+        xr = nchw(x).requires_grad_()
+        g_, b_ = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        ref = F.silu(F.group_norm(xr, 8, g_, b_, 1e-5))
+        gx, gg, gb = torch.autograd.grad(ref, [xr, g_, b_], nchw(dy))
+        assert_close(nchw(dx1), gx, BF, "one-pass dx vs autograd")
+        assert_close(dg1 - 0.25, gg, 5e-3, "dgamma vs autograd")
+        assert_close(db1 + 0.5, gb, 5e-3, "dbeta vs autograd")
+    # bit-reproducible: a second run gives the same bits
+    dx1b, dg1b, db1b, _, _ = run("18" if big else None)
+    assert torch.equal(dx1, dx1b) and torch.equal(dg1, dg1b) and torch.equal(db1, db1b)
 
 
 def test_gn_silu_bwd_fused_column_sums():
