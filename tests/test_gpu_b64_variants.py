@@ -212,7 +212,8 @@ def test_wgrad_linear_full_size(K, M, Kd, N):
     dy = q16(rnd(M, N, seed=2))
     dw, db = torch.zeros(N, Kd, device=dev()), torch.zeros(N, device=dev())
     K.wgrad(x.to(torch.bfloat16), dy.to(torch.bfloat16), dw, db, taps=1)
-    assert K.last_variant() == "wgrad<TH=8,TW=16,S=1,MODE=4,TAPS=1>"
+    # 256 input channels and more: two 64-channel ci sub-tiles per workgroup (dm_wgrad.hip, CIW)
+    assert K.last_variant() == ("wgrad<TH=8,TW=16,S=1,MODE=4,TAPS=1,CIW=2>" if Kd >= 256 else "wgrad<TH=8,TW=16,S=1,MODE=4,TAPS=1>")
     assert_close(dw, (dy.double().t() @ x.double()).float(), 5e-3, "linear wgrad")
     assert_close(db, dy.double().sum(0).float(), 5e-3, "linear bias grad")
     dw2, db2 = torch.zeros(N, Kd, device=dev()), torch.zeros(N, device=dev())
