@@ -340,7 +340,9 @@ def _side_stream(device):
     key = device.index or 0
     st = _SIDE.get(key)
     if st is None:
-        st = (torch.cuda.Stream(device=device), torch.cuda.Event())
+        prio = os.environ.get("DM_SIDE_PRIORITY", "")   # developer switch (tools/prio_ab.sh)
+        stream = _stream_with_priority(device, int(prio)) if prio else torch.cuda.Stream(device=device)
+        st = (stream, torch.cuda.Event())
         _SIDE[key] = st
     return st
 
@@ -404,11 +406,32 @@ _AUX_DIRTY = set()
 _AUX_JOIN_EV = {}   # per device: the event call_on_side records on the auxiliary stream (aux -> side join)
 
 
+def _stream_with_priority(device, priority: int):
+    """A HIP stream of the given priority (hipStreamCreateWithPriority: -1 high, 0 normal, 1 low on this runtime; torch's
+    own constructor only offers 0 and negative values) wrapped for torch.  The stream lives until the process ends."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = non-blocking
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipStreamCreateWithPriority failed ({rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 def aux_stream(device):
     key = torch.device(device).index or 0
     st = _AUX.get(key)
     if st is None:
-        st = (torch.cuda.Stream(device=device), torch.cuda.Event())
+        # LOW priority by default: what runs here (the dead-attention branch of the one-token configuration) has the whole
+        # step to finish in, so the dispatcher should hand free CUs to the main chain and the weight gradients first.  Same-box
+        # A/B (tools/prio_ab.sh, three alternating runs): 14.751 ms per step against 14.783 at equal priority (-0.2 %),
+        # 14.894 with this stream HIGH (+0.8 %), 14.837 with the weight-gradient stream low: the step is bound by total
+        # throughput, not by its critical path, and priorities move it little.  DM_AUX_PRIORITY=0 restores a plain stream.
+        prio = os.environ.get("DM_AUX_PRIORITY", "1")
+        dev = torch.device(device)
+        stream = _stream_with_priority(dev, int(prio)) if prio not in ("", "0") else torch.cuda.Stream(device=dev)
+        st = (stream, torch.cuda.Event())
         _AUX[key] = st
     return st
 
