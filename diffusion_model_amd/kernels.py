@@ -341,7 +341,7 @@ def _side_stream(device):
     st = _SIDE.get(key)
     if st is None:
         prio = os.environ.get("DM_SIDE_PRIORITY", "")   # developer switch (tools/prio_ab.sh)
-        stream = _stream_with_priority(device, int(prio)) if prio else torch.cuda.Stream(device=device)
+        stream = _stream_with_priority(device, int(prio)) if prio not in ("", "0") else torch.cuda.Stream(device=device)
         st = (stream, torch.cuda.Event())
         _SIDE[key] = st
     return st
@@ -423,12 +423,12 @@ def aux_stream(device):
     key = torch.device(device).index or 0
     st = _AUX.get(key)
     if st is None:
-        # LOW priority by default: what runs here (the dead-attention branch of the one-token configuration) has the whole
-        # step to finish in, so the dispatcher should hand free CUs to the main chain and the weight gradients first.  Same-box
-        # A/B (tools/prio_ab.sh, three alternating runs): 14.751 ms per step against 14.783 at equal priority (-0.2 %),
-        # 14.894 with this stream HIGH (+0.8 %), 14.837 with the weight-gradient stream low: the step is bound by total
-        # throughput, not by its critical path, and priorities move it little.  DM_AUX_PRIORITY=0 restores a plain stream.
-        prio = os.environ.get("DM_AUX_PRIORITY", "1")
+        # Priorities were measured and left off (DM_AUX_PRIORITY / DM_SIDE_PRIORITY stay as developer switches, tools/prio_ab.sh):
+        # this stream LOW gave 14.751 ms per step against 14.783 at equal priority (-0.2 %), HIGH 14.894 (+0.8 %), the
+        # weight-gradient stream low 14.837 -- the step is bound by total throughput, not by its critical path -- and a
+        # priority stream in the process made every HIP-graph replay 2.5x slower (MNIST leg 1.75 -> 4.4 ms per step,
+        # tools/mnist_ab.sh), whether or not the graph uses it.
+        prio = os.environ.get("DM_AUX_PRIORITY", "")
         dev = torch.device(device)
         stream = _stream_with_priority(dev, int(prio)) if prio not in ("", "0") else torch.cuda.Stream(device=dev)
         st = (stream, torch.cuda.Event())
