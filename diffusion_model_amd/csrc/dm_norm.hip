@@ -836,6 +836,23 @@ __global__ __launch_bounds__(256) void gn_param_final_kernel(const float* __rest
   }
 }
 
+// One-stage form for few rows (the one-pass backward leaves ONE row per sample): thread f adds the R rows in order into
+// dgamma / dbeta, the threads behind add the per-sample column sums of dx.  One launch instead of two on the backward's
+// critical path (the small-shape configurations are launch-gap bound).
+__global__ __launch_bounds__(256) void gn_param_rows_kernel(const float* __restrict__ ws, int R, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, const float* __restrict__ colpart,
+                                                            float* __restrict__ dx_colsum, int B, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * C) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < R; ++r) a += ws[(long)r * 2 * C + i];
+    ((i & 1) ? dgamma : dbeta)[i >> 1] += a;
+  } else if (dx_colsum && i - 2 * C < B * C) {
+    dx_colsum[i - 2 * C] += colpart[i - 2 * C];
+  }
+}
+
 // Pixel chunks per sample.  Every workgroup pays a fixed prologue (per-channel affine rows, the merge of the partial
 // table, a barrier), so few fat workgroups beat many thin ones: tools/hbmbench.py, B=64, workgroups in total
 // 2048 -> 512 (forward) / 768 (backward): 128ch@48x48 40.8 -> 29.9 us / 65.2 -> 49.3, 256ch@24x24 24.5 -> 19.3 / 36.8 ->
@@ -962,10 +979,16 @@ extern "C" int dm_gn_silu_bwd(const void* x, long ldx, const float* chan_add, co
 #undef DM_OPB
     if (rc != DM_OK) return rc;
     DM_LAUNCH_CHECK();
-    const int RB1 = B < 16 ? B : 16;
+    const int nfin1 = 2 * C + (dx_colsum ? B * C : 0);
+    if (B <= 256) {
+      hipLaunchKernelGGL(gn_param_rows_kernel, dim3((nfin1 + 255) / 256), dim3(256), 0, st, ws, B, dgamma, dbeta, colpart1,
+                         dx_colsum, B, C);
+      DM_LAUNCH_CHECK();
+      return DM_OK;
+    }
+    const int RB1 = 16;
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3((2 * C + 63) / 64, RB1), dim3(256), 0, st, ws, wsp1, B, C);
     DM_LAUNCH_CHECK();
-    const int nfin1 = 2 * C + (dx_colsum ? B * C : 0);
     hipLaunchKernelGGL(gn_param_final_kernel, dim3((nfin1 + 255) / 256), dim3(256), 0, st, wsp1, RB1, dgamma, dbeta, colpart1,
                        dx_colsum, B, C, 1);
     DM_LAUNCH_CHECK();
