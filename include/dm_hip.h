@@ -159,7 +159,9 @@ int dm_gn_prepare(const void* x, long ldx, const float* chan_add, const float* g
                   void* workspace, long ws_bytes, dm_stream_t stream);
 /* dx = d/dx of the above (+ add_in), optional dropout mask (the mask dm_conv3x3 applied to x);
  * dgamma/dbeta accumulated (+=).  All three reductions (dgamma, dbeta, dx_colsum) are summed in a fixed order through
- * workspace partials (no atomics): the same inputs give the same bits.
+ * workspace partials (no atomics): the same inputs give the same bits.  Groups of 16 channels and more whose (sample, group)
+ * slab is at most 72 KiB take a one-pass kernel (x and dy read once: 6 instead of 10 bytes per element); the result differs
+ * from the two-pass kernels' only through the summation order of the group means.
  * dx_colsum (optional, [B][C] fp32, accumulated +=): per-sample channel sums
  * of the written dx = the gradient of the time-embedding projection / conv1 bias of the ResBlock
  * (unet.py:101-102), produced in the same pass instead of a separate reduction over dx. */
