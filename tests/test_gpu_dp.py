@@ -1,4 +1,4 @@
-"""configs[2] on real kernels: the data-parallel training step with TWO (and FOUR) ranks.  One GPU box has one GPU and RCCL refuses
+"""configs[2] on real kernels: the data-parallel training step with TWO (and FOUR, and configs[2]'s EIGHT) ranks.  One GPU box has one GPU and RCCL refuses
 two ranks on one device, so the ranks share cuda:0 and exchange gradients over gloo -- the Trainer, the bucket hook on
 the weight-gradient side stream (ordered behind the main AND the auxiliary stream, kernels.call_on_side), the broadcast
 of the replicas and the fused clip + AdamW + EMA are exactly the N > 1 code path; only the transport differs from RCCL:
@@ -112,7 +112,8 @@ def _worker_body(rank, world, port, q, side_wgrad):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("side_wgrad,world", [(True, 2), (False, 2), (True, 4)], ids=["side_wgrad", "inline_wgrad", "four_ranks"])
+@pytest.mark.parametrize("side_wgrad,world", [(True, 2), (False, 2), (True, 4), (True, 8)],
+                         ids=["side_wgrad", "inline_wgrad", "four_ranks", "eight_ranks"])   # eight = configs[2]'s world size
 def test_data_parallel_ranks_match_gradient_accumulation(side_wgrad, world):
     import queue as _queue
     import socket
