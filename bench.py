@@ -732,9 +732,11 @@ def _run(a, real_stdout):
         "collective": "RCCL all-reduce (torch.distributed nccl backend), 6 buckets, only on accumulation boundaries"
                       if world > 1 else None,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        # (the compute dtype of the headline legs: bf16 unless the process was started with DM_COMPUTE_DTYPE=fp32)
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if K.ACT[0] == torch.float32 else "bf16",
         "data": "synthetic", "final_loss": final_loss,
-        "config": {"workload": "configs[1]: main_stl10 UNet v-pred train step 96x96x3, B=64/GPU bf16, AdamW+EMA+clip, "
+        "config": {"workload": "configs[1]: main_stl10 UNet v-pred train step 96x96x3, B=64/GPU "
+                               + ("f32" if K.ACT[0] == torch.float32 else "bf16") + ", AdamW+EMA+clip, "
                                "accumulation 2 (step = 1 optimizer step = 128 img/GPU), CLIP ctx, low-t weighting",
                    "global_batch": 2 * a.batch * world, "micro_batch": a.batch, "dropout": a.dropout,
                    "parallelism": f"dp{world}", "weights": "reference init (seed 0), output_conv N(0,0.05^2)"},

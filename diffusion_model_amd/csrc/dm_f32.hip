@@ -290,13 +290,34 @@ __global__ void wgrad_f32_reduce_kernel(const float* __restrict__ slab, float* _
 // column sums in two ordered stages: part[chunk][c] = sum of the chunk's rows; out[c] (+)= sum over chunks
 __global__ __launch_bounds__(256) void colsum_part_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ part,
                                                                long rows, int C, int nchunk) {
-  const int chunk = blockIdx.x;
+  // all 256 threads work whatever C is: 256 / cw row lanes per column block of cw <= 256 columns, four independent loads in
+  // flight per thread, the row lanes combined in lane order through LDS (fixed order: bit-reproducible)
+  __shared__ float red[256];
+  const int chunk = blockIdx.x, tid = threadIdx.x;
   const long per = (rows + nchunk - 1) / nchunk;
   const long r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f;
-    for (long r = r0; r < r1; ++r) a += x[r * ldx + c];
-    part[(long)chunk * C + c] = a;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int cw = C - c0 < 256 ? C - c0 : 256;
+    const int nl = 256 / cw, rl = tid / cw, c = c0 + tid % cw;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (rl < nl) {
+      long r = r0 + rl;
+      for (; r + 3 * nl < r1; r += 4 * nl) {
+        a0 += x[r * ldx + c];
+        a1 += x[(r + nl) * ldx + c];
+        a2 += x[(r + 2 * nl) * ldx + c];
+        a3 += x[(r + 3 * nl) * ldx + c];
+      }
+      for (; r < r1; r += nl) a0 += x[r * ldx + c];
+    }
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < cw) {
+      float sum = 0.f;
+      for (int l = 0; l < nl; ++l) sum += red[l * cw + tid];
+      part[(long)chunk * C + c0 + tid] = sum;
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void colsum_batch_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
@@ -310,11 +331,23 @@ __global__ __launch_bounds__(256) void colsum_batch_f32_kernel(const float* __re
 }
 __global__ void colsum_final_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nchunk, int n_valid,
                                         int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_valid) return;
-  float a = 0.f;
-  for (int k = 0; k < nchunk; ++k) a += part[(long)k * C + c];
-  if (accumulate) out[c] += a; else out[c] = a;
+  // 16 columns per 256-thread block, 16 chunk lanes per column (independent loads, lanes combined in order)
+  __shared__ float red[256];
+  const int tid = threadIdx.x, cl = tid & 15, kl = tid >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < n_valid) {
+    int k = kl;
+    for (; k + 16 < nchunk; k += 32) { a0 += part[(long)k * C + c]; a1 += part[(long)(k + 16) * C + c]; }
+    if (k < nchunk) a0 += part[(long)k * C + c];
+  }
+  red[tid] = a0 + a1;
+  __syncthreads();
+  if (tid < 16 && c < n_valid) {
+    float sum = 0.f;
+    for (int l = 0; l < 16; ++l) sum += red[l * 16 + tid];
+    if (accumulate) out[c] += sum; else out[c] = sum;
+  }
 }
 
 // ------------------------------------------------------------------ GroupNorm + SiLU
@@ -731,7 +764,7 @@ int wgrad_f32_nsplit(long M, int Cip, int Cop, int taps) {
   if (ns > 256) ns = 256;
   return (int)ns;
 }
-constexpr int COLSUM_CHUNKS = 256;
+constexpr int COLSUM_CHUNKS = 1024;   // (256 chunks left the 590k-row layers at 1.6 TB/s: one workgroup per CU, four row lanes)
 
 template <int HD, int P>
 int launch_attn_f32(const AttnF& p, int which, hipStream_t st) {
@@ -880,7 +913,7 @@ extern "C" int dm_wgrad_f32(const dm_wgrad_args* a, dm_stream_t stream) {
     hipLaunchKernelGGL(colsum_part_f32_kernel, dim3(COLSUM_CHUNKS), dim3(256), 0, st, p.dy, p.lddy, part, p.M, a->Cout,
                        COLSUM_CHUNKS);
     DM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_f32_kernel, dim3((n_valid + 255) / 256), dim3(256), 0, st, part, a->dbias, a->Cout,
+    hipLaunchKernelGGL(colsum_final_f32_kernel, dim3((n_valid + 15) / 16), dim3(256), 0, st, part, a->dbias, a->Cout,
                        COLSUM_CHUNKS, n_valid, 1);
     DM_LAUNCH_CHECK();
   }
